@@ -1,0 +1,91 @@
+"""ctypes binding of libgcnn_hip.so (C ABI declared in include/gcnn_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is raised."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")
+ABI_VERSION = 1
+
+
+class GcnnError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [("n_cons", C.c_int32), ("n_vars", C.c_int32), ("n_cuts", C.c_int32),
+                ("n_cons_edges", C.c_int32), ("n_cut_edges", C.c_int32)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("l_ptr", C.c_void_p), ("l_oth", C.c_void_p), ("l_coef", C.c_void_p),
+                ("v_ptr", C.c_void_p), ("v_oth", C.c_void_p), ("v_coef", C.c_void_p)]
+
+
+_P, _I, _F, _Z = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+_DP, _GP = C.POINTER(Dims), C.POINTER(Graph)
+
+# name -> (restype, argtypes); every symbol include/gcnn_hip.h declares
+SIGNATURES = {
+    "gcnn_abi_version": (C.c_int, []),
+    "gcnn_param_count": (C.c_int, []),
+    "gcnn_param_total_floats": (C.c_int, []),
+    "gcnn_param_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
+    "gcnn_graph_temp_bytes": (_Z, [_I]),
+    "gcnn_graph_build": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "gcnn_seg_sum_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
+    "gcnn_seg_bcast_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
+    "gcnn_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
+    "gcnn_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_conv_edge_bwd_partials": (_I, [_I, _I]),
+    "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_workspace_floats": (_Z, [_DP]),
+    "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P]),
+    "gcnn_mse_loss": (C.c_int, [_P, _P, _I, _F, _P, _P, _P]),
+    "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P]),
+    "gcnn_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises GcnnError when it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GcnnError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(or gcnn-cut-selector_amd/csrc/build.sh); there is no CPU fallback")
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as exc:  # pragma: no cover
+            raise GcnnError(f"cannot load {LIB_PATH}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.gcnn_abi_version() != ABI_VERSION:
+            raise GcnnError(f"ABI mismatch: library {handle.gcnn_abi_version()} vs binding {ABI_VERSION}; rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "workspace too small"}.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
+        raise GcnnError(f"{what} failed: {kind}")
+
+
+def param_layout():
+    """[(offset, rows, cols, trainable)] for the 62 checkpoint arrays, and the flat buffer size, from the library."""
+    handle = lib()
+    out = []
+    for i in range(handle.gcnn_param_count()):
+        off, rows, cols, tr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(handle.gcnn_param_info(i, C.byref(off), C.byref(rows), C.byref(cols), C.byref(tr)), "gcnn_param_info")
+        out.append((off.value, rows.value, cols.value, bool(tr.value)))
+    return out, handle.gcnn_param_total_floats()

@@ -1,0 +1,1221 @@
+// gcnn_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels + C ABI for the bipartite GCNN hot path.
+//
+// Reference semantics (all cites into /root/reference): GCNN.call model.py:257-300, PartialGraphConvolution.call
+// model.py:533-575, PreNormLayer.call model.py:365-382, loss/step model_trainer.py:266-273.
+//
+// Design: every node tensor is a row-major [N,64] fp32 matrix (256-B rows).  The per-edge
+// Dense(64->64) of the reference (model.py:499-500) is hoisted past the scatter-sum
+//   sum_e (H_e W_f + b_f) = (sum_e H_e) W_f + deg_r b_f
+// so the edge pass only gathers rows, applies ReLU and accumulates in registers (atomic-free segmented sum over
+// receiver-sorted CSR); all 64x64 products run on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with weights staged in LDS.
+// Wavefront = 64 lanes everywhere.  No atomics on floats anywhere: every sum has a fixed order => bitwise
+// reproducible results.
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/gcnn_hip.h"
+
+#define EMB 64
+#define LDW 68  // padded LDS row stride in floats: 272 B keeps 16-B alignment, b128 row reads conflict-free
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// parameter layout (checkpoint order, model.py:53-56/215; shapes model.py:174-208, 486-508)
+// ---------------------------------------------------------------------------------------------------------------
+struct PInfo { int off, rows, cols, trainable; };
+static PInfo g_pinfo[GCNN_N_PARAMS];
+static int g_ptotal = 0;
+
+enum {  // indices into the 62-array list
+    P_CONS = 0, P_CONS_EDGE = 6, P_VAR = 8, P_CUT = 14, P_CUT_EDGE = 20, P_CONV0 = 22, P_CONV1 = 34, P_CONV2 = 46,
+    P_OUT = 58
+};
+enum { E_SHIFT = 0, E_SCALE = 1, E_W1 = 2, E_B1 = 3, E_W2 = 4, E_B2 = 5 };  // embedding block
+enum { C_WL = 0, C_BL = 1, C_WE = 2, C_WR = 3, C_S1 = 4, C_WF = 5, C_BF = 6, C_S2 = 7, C_W1 = 8, C_B1 = 9, C_W2 = 10,
+       C_B2 = 11 };  // conv block
+
+static void layout_init() {
+    if (g_ptotal) return;
+    int n = 0, off = 0;
+    auto add = [&](int rows, int cols, int tr) {
+        g_pinfo[n].off = off; g_pinfo[n].rows = rows; g_pinfo[n].cols = cols; g_pinfo[n].trainable = tr;
+        off += (rows * cols + 3) & ~3; ++n;
+    };
+    auto emb = [&](int f) { add(1, f, 0); add(1, f, 0); add(f, EMB, 1); add(1, EMB, 1); add(EMB, EMB, 1); add(1, EMB, 1); };
+    auto conv = [&]() {
+        add(EMB, EMB, 1); add(1, EMB, 1); add(1, EMB, 1); add(EMB, EMB, 1); add(1, 1, 0); add(EMB, EMB, 1); add(1, EMB, 1);
+        add(1, 1, 0); add(2 * EMB, EMB, 1); add(1, EMB, 1); add(EMB, EMB, 1); add(1, EMB, 1);
+    };
+    emb(4); add(1, 1, 0); add(1, 1, 0); emb(14); emb(6); add(1, 1, 0); add(1, 1, 0);
+    conv(); conv(); conv();
+    add(EMB, EMB, 1); add(1, EMB, 1); add(EMB, 1, 1); add(1, 1, 1);
+    g_ptotal = off;
+}
+static inline int poff(int i) { return g_pinfo[i].off; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch).  Give every XCD a contiguous range of work items so the
+// rows a range gathers stay in that XCD's 4 MiB L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// joint pre-activation of one edge, in the reference's association order: (left + coef*w) + right, model.py:564-565
+__device__ __forceinline__ float jointf(float pl, float cw, float pr) { return __fadd_rn(__fadd_rn(pl, cw), pr); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2a: first embedding layer, relu(((x+shift)*scale) @ W[f,64] + b)      model.py:174-177 (and var/cut twins)
+// 16 lanes per row, 4 channels per lane.  F <= 16.
+// ---------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void k_embed1_fwd(const float* __restrict__ x, const float* __restrict__ shift,
+                                                    const float* __restrict__ scale, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float* __restrict__ y, int n) {
+    const int ch = (threadIdx.x & 15) * 4;
+    float4 wr[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) wr[f] = *(const float4*)(w + f * EMB + ch);
+    const float4 bb = *(const float4*)(b + ch);
+    float sh[F], sc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { sh[f] = shift[f]; sc[f] = scale[f]; }
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += gridDim.x * 16) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float xv = (x[(size_t)r * F + f] + sh[f]) * sc[f];
+            acc.x = fmaf(xv, wr[f].x, acc.x); acc.y = fmaf(xv, wr[f].y, acc.y);
+            acc.z = fmaf(xv, wr[f].z, acc.z); acc.w = fmaf(xv, wr[f].w, acc.w);
+        }
+        acc.x = fmaxf(acc.x + bb.x, 0.f); acc.y = fmaxf(acc.y + bb.y, 0.f);
+        acc.z = fmaxf(acc.z + bb.z, 0.f); acc.w = fmaxf(acc.w + bb.w, 0.f);
+        *(float4*)(y + (size_t)r * EMB + ch) = acc;
+    }
+}
+
+// gradient of the first embedding layer's weights: dW[f][j] = sum_r xn[r][f] * dPre[r][j], db[j] = sum_r dPre[r][j]
+// with dPre = dY * (Y > 0).  One block per chunk of rows; per-block partial slab [(F+1)*64] (row F = bias).
+template <int F>
+__global__ __launch_bounds__(256) void k_embed1_wgrad(const float* __restrict__ x, const float* __restrict__ shift,
+                                                      const float* __restrict__ scale, const float* __restrict__ dy,
+                                                      const float* __restrict__ yact, float* __restrict__ partial,
+                                                      int n, int rows_per_block) {
+    __shared__ float red[4][(F + 1) * EMB];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    float acc[F + 1];
+#pragma unroll
+    for (int f = 0; f <= F; ++f) acc[f] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    for (int r = r0 + part; r < r1; r += 4) {
+        float d = dy[(size_t)r * EMB + col];
+        d = yact[(size_t)r * EMB + col] > 0.f ? d : 0.f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = fmaf((x[(size_t)r * F + f] + shift[f]) * scale[f], d, acc[f]);
+        acc[F] += d;
+    }
+#pragma unroll
+    for (int f = 0; f <= F; ++f) red[part][f * EMB + col] = acc[f];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (F + 1) * EMB; i += 256)
+        partial[(size_t)blockIdx.x * (F + 1) * EMB + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3/K4/K8'/K11/K12 and their input gradients: the generic 64-wide node GEMM on fp32 MFMA.
+//
+//   NN mode (forward):   y  = act( (sa*xa) @ wa  [+ xb @ wb] [+ bias] [+ deg (x) bd] )
+//   TN mode (backward):  xa' = xa * (ymask > 0) (written back in place when write_back), then
+//                        y  (=|+=) so * (xa' @ wa^T)      and optionally      y2 (=|+=) xa' @ wb^T
+//
+// Block = 4 waves; each wave owns a 32-row tile: stage rows in LDS (full 256-B lines, coalesced), read A fragments as
+// b128 along k.  The k index is split between the two lane halves (half h takes k in [32h, 32h+32)): the order of the
+// 64 products in each dot product is 0,32,1,33,... (exact fp32 FMA chain, different association than a CPU GEMM).
+// Weights sit in LDS as [64][LDW]; B fragments are b32 reads along a row (NN) or b128 reads along k (TN), both
+// conflict-free with LDW = 68.
+// ---------------------------------------------------------------------------------------------------------------
+struct LinArgs {
+    const float* xa; const float* ymask; int write_back;
+    const float* sa;
+    const float* wa; const float* xb; const float* wb;
+    const float* bias; const float* bd; const int* seg_ptr;
+    const float* so;
+    float* y; int beta_y; float* y2; int beta_y2;
+    int relu; int n;
+};
+
+__device__ __forceinline__ void block_load_w(float* wl, const float* __restrict__ w) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + threadIdx.x;  // float4 index, 1024 of them
+        const int r = idx >> 4, c = (idx & 15) * 4;
+        *(float4*)(wl + r * LDW + c) = *(const float4*)(w + r * EMB + c);
+    }
+}
+
+__device__ __forceinline__ void wave_load_tile(float* xs, const float* __restrict__ x, int row0, int n, float scale,
+                                               const float* __restrict__ ymask, int write_back, float* xwb, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 4 + (lane >> 4), c = (lane & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < n) {
+            const size_t o = (size_t)(row0 + r) * EMB + c;
+            v = *(const float4*)(x + o);
+            if (ymask) {
+                const float4 m = *(const float4*)(ymask + o);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+                v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                if (write_back) *(float4*)(xwb + o) = v;
+            }
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        }
+        *(float4*)(xs + r * LDW + c) = v;
+    }
+}
+
+template <bool TRANSB>
+__device__ __forceinline__ void wave_gemm(const float* xs, const float* wl, f32x16 (&acc)[2], int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 a = *(const float4*)(xs + r * LDW + h * 32 + q * 4);
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        if (TRANSB) {
+            const float4 b0 = *(const float4*)(wl + r * LDW + h * 32 + q * 4);
+            const float4 b1 = *(const float4*)(wl + (32 + r) * LDW + h * 32 + q * 4);
+            const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0] = mfma32(av[t], b0v[t], acc[0]);
+                acc[1] = mfma32(av[t], b1v[t], acc[1]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = h * 32 + q * 4 + t;
+                acc[0] = mfma32(av[t], wl[k * LDW + r], acc[0]);
+                acc[1] = mfma32(av[t], wl[k * LDW + 32 + r], acc[1]);
+            }
+        }
+    }
+}
+
+// accumulator (C/D layout: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)) -> row-major LDS tile
+__device__ __forceinline__ void wave_acc_to_tile(float* xs, const f32x16 (&acc)[2], int lane) {
+    const int j = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xs[((i & 3) + 8 * (i >> 2) + 4 * hh) * LDW + ct * 32 + j] = acc[ct][i];
+}
+
+__device__ __forceinline__ void wave_store_tile(const float* xs, float* __restrict__ y, int row0, int n, int beta,
+                                                int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = i * 4 + (lane >> 4), c = (lane & 15) * 4;
+        if (row0 + r < n) {
+            float4 v = *(const float4*)(xs + r * LDW + c);
+            float* dst = y + (size_t)(row0 + r) * EMB + c;
+            if (beta) {
+                const float4 o = *(const float4*)dst;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *(float4*)dst = v;
+        }
+    }
+}
+
+template <bool TRANSB>
+__global__ __launch_bounds__(256) void k_linear(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wla = smem;                                  // [64][LDW]
+    float* wlb = smem + 64 * LDW;                       // [64][LDW] (second weight, optional)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* xs = smem + 2 * 64 * LDW + wv * 32 * LDW;    // per-wave [32][LDW] tile
+
+    block_load_w(wla, a.wa);
+    if (a.wb) block_load_w(wlb, a.wb);
+    __syncthreads();
+
+    const float sa = a.sa ? *a.sa : 1.f;
+    const float so = a.so ? *a.so : 1.f;
+    const int j = lane & 31, hh = lane >> 5;
+    const int ntile = (a.n + 31) >> 5;
+    for (int tile = blockIdx.x * 4 + wv; tile < ntile; tile += gridDim.x * 4) {
+        const int row0 = tile * 32;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+        wave_load_tile(xs, a.xa, row0, a.n, sa, a.ymask, a.write_back, const_cast<float*>(a.xa), lane);
+        wave_gemm<TRANSB>(xs, wla, acc, lane);
+        if (!TRANSB) {
+            if (a.xb) {
+                wave_load_tile(xs, a.xb, row0, a.n, 1.f, nullptr, 0, nullptr, lane);
+                wave_gemm<false>(xs, wlb, acc, lane);
+            }
+            // epilogue: bias, degree-weighted bias (the hoisted b_f, model.py:499-500 + 568), activation
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const float bv = a.bias ? a.bias[ct * 32 + j] : 0.f;
+                const float bdv = a.bd ? a.bd[ct * 32 + j] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[ct][i] + bv;
+                    if (a.bd) {
+                        const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        const float deg = row < a.n ? (float)(a.seg_ptr[row + 1] - a.seg_ptr[row]) : 0.f;
+                        v = fmaf(deg, bdv, v);
+                    }
+                    acc[ct][i] = a.relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+            wave_acc_to_tile(xs, acc, lane);
+            wave_store_tile(xs, a.y, row0, a.n, a.beta_y, lane);
+        } else {
+            f32x16 acc2[2];
+            if (a.y2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { acc2[0][i] = 0.f; acc2[1][i] = 0.f; }
+                wave_gemm<true>(xs, wlb, acc2, lane);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ct][i] *= so;
+            wave_acc_to_tile(xs, acc, lane);
+            wave_store_tile(xs, a.y, row0, a.n, a.beta_y, lane);
+            if (a.y2) {
+                wave_acc_to_tile(xs, acc2, lane);
+                wave_store_tile(xs, a.y2, row0, a.n, a.beta_y2, lane);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
+// Grouped launch: one job per (X, D) pair, one block per 256-row chunk of a job.  Wave w owns the 32x32 quadrant
+// (w>>1, w&1) of G; rows are the MFMA k dimension.  Per-block partial slab [64*64 + 64 + 64] floats; summed in a
+// fixed order by k_reduce (no atomics).
+// ---------------------------------------------------------------------------------------------------------------
+#define WG_ROWS 256
+#define WG_SLAB (EMB * EMB + 2 * EMB)
+#define WG_MAX_JOBS 24
+struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; int n; int blk0; int slab0; };
+struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[64 * LDW];
+    __shared__ __attribute__((aligned(16))) float ds[64 * LDW];
+    __shared__ float red[4][2 * EMB];
+    int ji = 0;
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
+    const WgJob jb = a.job[ji];
+    const int lb = blockIdx.x - jb.blk0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qi = wv >> 1, qj = wv & 1, i32 = lane & 31, h = lane >> 5;
+    const float sx = jb.sx ? *jb.sx : 1.f;
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float cs = 0.f, cds = 0.f;
+    const int rbeg = lb * WG_ROWS, rend = min(jb.n, rbeg + WG_ROWS);
+    for (int row0 = rbeg; row0 < rend; row0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // 64 rows x 16 float4 = 1024 float4 per matrix
+            const int idx = i * 256 + threadIdx.x;
+            const int r = idx >> 4, c = (idx & 15) * 4;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
+            if (row0 + r < rend) {
+                xv = *(const float4*)(jb.x + (size_t)(row0 + r) * EMB + c);
+                dv = *(const float4*)(jb.d + (size_t)(row0 + r) * EMB + c);
+                xv.x *= sx; xv.y *= sx; xv.z *= sx; xv.w *= sx;
+            }
+            *(float4*)(xs + r * LDW + c) = xv;
+            *(float4*)(ds + r * LDW + c) = dv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const int r = h * 32 + s;
+            acc = mfma32(xs[r * LDW + qi * 32 + i32], ds[r * LDW + qj * 32 + i32], acc);
+        }
+        // column sums of D (bias grads), 16 rows per thread
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int r = part * 16 + s;
+            const float dv = ds[r * LDW + col];
+            cs += dv;
+            if (jb.seg_ptr) {
+                const int gr = row0 + r;
+                const float deg = gr < rend ? (float)(jb.seg_ptr[gr + 1] - jb.seg_ptr[gr]) : 0.f;
+                cds = fmaf(deg, dv, cds);
+            }
+        }
+    }
+    float* slab = a.partial + (size_t)(jb.slab0 + lb) * WG_SLAB;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        slab[(qi * 32 + row) * EMB + qj * 32 + i32] = acc[i];
+    }
+    red[part][col] = cs; red[part][EMB + col] = cds;
+    __syncthreads();
+    if (threadIdx.x < 2 * EMB)
+        slab[EMB * EMB + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Fixed-order sum of partial slabs into the flat gradient buffer.  One block per (job, 64-float chunk).
+#define RD_MAX_JOBS 96
+struct RdJob { const float* src; float* dst; int nparts; int stride; int len; int blk0; };
+struct RdArgs { int njobs; RdJob job[RD_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
+    __shared__ float red[4][EMB];
+    int ji = 0;
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
+    const RdJob jb = a.job[ji];
+    const int chunk = blockIdx.x - jb.blk0;
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int e = chunk * EMB + col;
+    float s = 0.f;
+    if (e < jb.len)
+        for (int p = part; p < jb.nparts; p += 4) s += jb.src[(size_t)p * jb.stride + e];
+    red[part][col] = s;
+    __syncthreads();
+    if (part == 0 && e < jb.len) jb.dst[e] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Edge pass (K5-K7 + K9 fused, K8 hoisted): S[r] = sum_{e in seg(r)} relu(s1 * ((PL[l_e] + c_e*w) + PR[v_e]))
+// with c_e = (coef_e + e_shift) * e_scale (the edge PreNorm, model.py:288/291).
+// G = 16*SLOTS lanes cooperate on one receiver: 16 lanes x float4 cover the 64 channels, SLOTS edges in flight per
+// step and 4 steps unrolled => up to 4*SLOTS independent 256-B row gathers per receiver.  The segment's (index, coef)
+// pairs are loaded coalesced, one per lane, and broadcast with wave shuffles.  Slot partial sums are combined in a
+// fixed order.  OWNER_LEFT: the node that owns the segment is the left node (constraint/cut) -- the receiver of
+// conv v->c / v->k (model.py:553-556) in MODE 0/1, the sender of conv c->v in MODE 2.
+// ---------------------------------------------------------------------------------------------------------------
+struct EdgeArgs {
+    const int* seg_ptr; const int* oth; const float* coef;
+    const float* p_recv; const float* p_oth;      // projected tables [R,64], [Nother,64]
+    const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
+    const float* d_s;                              // backward only: dS [R,64] (recv pass) or gathered (send pass)
+    float* out;                                    // S (fwd) / dP_recv / dP_send
+    float* dw_partial;                             // backward recv pass: per-block [64] partial of d w_edge
+    int n_recv;
+};
+
+template <int SLOTS>
+__device__ __forceinline__ float4 slot_reduce(float4 v) {
+    if (SLOTS >= 2) {
+        v.x += __shfl_xor(v.x, 16); v.y += __shfl_xor(v.y, 16); v.z += __shfl_xor(v.z, 16); v.w += __shfl_xor(v.w, 16);
+    }
+    if (SLOTS >= 4) {
+        v.x += __shfl_xor(v.x, 32); v.y += __shfl_xor(v.y, 32); v.z += __shfl_xor(v.z, 32); v.w += __shfl_xor(v.w, 32);
+    }
+    return v;
+}
+
+// MODE 0: forward; MODE 1: backward, receiver-ordered (dP_recv + d w_edge); MODE 2: backward, sender-ordered (dP_send:
+// here "recv" in the argument names means the node that owns the segment, i.e. the sender, and d_s is gathered).
+template <int SLOTS, bool OWNER_LEFT, int MODE>
+__global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
+    constexpr int G = 16 * SLOTS, RPW = 64 / G;
+    __shared__ float dwred[4][EMB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, ch = (gl & 15) * 4;
+    const float4 w = *(const float4*)(a.w_edge + ch);
+    const float esh = *a.e_shift, esc = *a.e_scale, s1 = *a.s1;
+    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int nwork = (a.n_recv + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
+    for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
+        const int r = item * RPW + lane / G;
+        if (r < a.n_recv) {
+            const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
+            const float4 pown = *(const float4*)(a.p_recv + (size_t)r * EMB + ch);
+            float4 down = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 1) down = *(const float4*)(a.d_s + (size_t)r * EMB + ch);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int base = beg; base < end; base += G) {
+                const int e = base + gl;
+                int o = 0; float c = 0.f;
+                if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
+                const int cnt = min(G, end - base);
+                for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
+                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4], dg[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u * SLOTS + slot;
+                        ok[u] = i < cnt;
+                        const int src = gbase + (ok[u] ? i : 0);
+                        oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        p[u] = make_float4(0.f, 0.f, 0.f, 0.f); dg[u] = p[u];
+                        if (ok[u]) {
+                            p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
+                            if (MODE == 2) dg[u] = *(const float4*)(a.d_s + (size_t)oi[u] * EMB + ch);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!ok[u]) continue;
+                        const float cw[4] = {__fmul_rn(ci[u], w.x), __fmul_rn(ci[u], w.y), __fmul_rn(ci[u], w.z),
+                                             __fmul_rn(ci[u], w.w)};
+                        const float pw[4] = {pown.x, pown.y, pown.z, pown.w};
+                        const float po[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
+                        float hj[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            hj[k] = s1 * (OWNER_LEFT ? jointf(pw[k], cw[k], po[k]) : jointf(po[k], cw[k], pw[k]));
+                        if (MODE == 0) {
+                            acc.x += fmaxf(hj[0], 0.f); acc.y += fmaxf(hj[1], 0.f);
+                            acc.z += fmaxf(hj[2], 0.f); acc.w += fmaxf(hj[3], 0.f);
+                        } else {
+                            const float4 dsv = MODE == 1 ? down : dg[u];
+                            const float dj[4] = {hj[0] > 0.f ? s1 * dsv.x : 0.f, hj[1] > 0.f ? s1 * dsv.y : 0.f,
+                                                 hj[2] > 0.f ? s1 * dsv.z : 0.f, hj[3] > 0.f ? s1 * dsv.w : 0.f};
+                            acc.x += dj[0]; acc.y += dj[1]; acc.z += dj[2]; acc.w += dj[3];
+                            if (MODE == 1) {
+                                dw.x = fmaf(ci[u], dj[0], dw.x); dw.y = fmaf(ci[u], dj[1], dw.y);
+                                dw.z = fmaf(ci[u], dj[2], dw.z); dw.w = fmaf(ci[u], dj[3], dw.w);
+                            }
+                        }
+                    }
+                }
+            }
+            acc = slot_reduce<SLOTS>(acc);
+            if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = acc;
+        }
+    }
+    if (MODE == 1) {
+        // lanes with equal channel group (lane & 15) hold partials of the same 4 channels: 4 per wave, 4 waves
+        dw.x += __shfl_xor(dw.x, 16); dw.y += __shfl_xor(dw.y, 16); dw.z += __shfl_xor(dw.z, 16); dw.w += __shfl_xor(dw.w, 16);
+        dw.x += __shfl_xor(dw.x, 32); dw.y += __shfl_xor(dw.y, 32); dw.z += __shfl_xor(dw.z, 32); dw.w += __shfl_xor(dw.w, 32);
+        if (lane < 16) *(float4*)(&dwred[wv][lane * 4]) = dw;
+        __syncthreads();
+        if (threadIdx.x < EMB)
+            a.dw_partial[(size_t)blockIdx.x * EMB + threadIdx.x] =
+                (dwred[0][threadIdx.x] + dwred[1][threadIdx.x]) + (dwred[2][threadIdx.x] + dwred[3][threadIdx.x]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K9 standalone: the scatter-sum pass as the reference defines it (tf.scatter_nd over [E,64] messages,
+// model.py:568-569) on receiver-sorted segments.  Pure streaming: 260 B/edge in, 256 B/receiver out.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SLOTS, bool PERM>
+__global__ __launch_bounds__(256) void k_seg_sum(const float* __restrict__ msg, const int* __restrict__ seg_ptr,
+                                                 const int* __restrict__ perm, int n_recv, float* __restrict__ out) {
+    constexpr int G = 16 * SLOTS, RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gl = lane % G, slot = gl >> 4, ch = (gl & 15) * 4;
+    const int nwork = (n_recv + RPW - 1) / RPW;
+    for (int item = blockIdx.x * 4 + wv; item < nwork; item += gridDim.x * 4) {
+        const int r = item * RPW + lane / G;
+        if (r >= n_recv) continue;
+        const int beg = seg_ptr[r], end = seg_ptr[r + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e0 = beg + slot; e0 < end; e0 += 4 * SLOTS) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * SLOTS;
+                p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < end) {
+                    const size_t row = PERM ? (size_t)perm[e] : (size_t)e;
+                    p[u] = *(const float4*)(msg + row * EMB + ch);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
+        }
+        acc = slot_reduce<SLOTS>(acc);
+        if (slot == 0) *(float4*)(out + (size_t)r * EMB + ch) = acc;
+    }
+}
+
+// transpose of the pass (gradient of tf.scatter_nd = row gather): d_msg[row(e)] = d_out[recv(e)]
+template <bool PERM>
+__global__ __launch_bounds__(256) void k_seg_bcast(const float* __restrict__ d_out, const int* __restrict__ seg_ptr,
+                                                   const int* __restrict__ perm, int n_recv, float* __restrict__ d_msg) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = lane >> 4, ch = (lane & 15) * 4;
+    for (int r = blockIdx.x * 4 + wv; r < n_recv; r += gridDim.x * 4) {
+        const int beg = seg_ptr[r], end = seg_ptr[r + 1];
+        const float4 v = *(const float4*)(d_out + (size_t)r * EMB + ch);
+        for (int e = beg + slot; e < end; e += 4) {
+            const size_t row = PERM ? (size_t)perm[e] : (size_t)e;
+            *(float4*)(d_msg + row * EMB + ch) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Readout tail Dense(64->1) (model.py:208, 299-300) and the loss head (model_trainer.py:271).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_score(const float* __restrict__ o1, const float* __restrict__ w2,
+                                               const float* __restrict__ b2, float* __restrict__ score, int n) {
+    const int ch = (threadIdx.x & 15) * 4;
+    const float4 w = *(const float4*)(w2 + ch);
+    const float b = *b2;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += gridDim.x * 16) {
+        const float4 v = *(const float4*)(o1 + (size_t)r * EMB + ch);
+        float s = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, v.w * w.w)));
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        if ((threadIdx.x & 15) == 0) score[r] = s + b;
+    }
+}
+
+// MSE head (model_trainer.py:271): loss = scale * sum_k (score_k - y_k)^2, d_score_k = 2*scale*(score_k - y_k).  One block.
+__global__ __launch_bounds__(256) void k_mse(const float* __restrict__ score, const float* __restrict__ target, float scale,
+                                             float* __restrict__ loss, float* __restrict__ d_score, int n) {
+    __shared__ float red[256];
+    float ls = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float d = score[k] - target[k];
+        ls = fmaf(d, d, ls);
+        if (d_score) d_score[k] = 2.f * d * scale;
+    }
+    red[threadIdx.x] = ls;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) *loss = red[0] * scale;
+}
+
+// gradient of Dense(64->1): dO1[k][j] = ds_k*w2[j]; dw2[j] = sum_k ds_k O1[k][j]; db2 = sum_k ds_k.  One block.
+__global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_score, const float* __restrict__ o1,
+                                                   const float* __restrict__ w2, float* __restrict__ d_o1,
+                                                   float* __restrict__ g_w2, float* __restrict__ g_b2, int n) {
+    __shared__ float red[4][EMB];
+    __shared__ float red2[256];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const float wj = w2[col];
+    float gw = 0.f;
+    for (int k = part; k < n; k += 4) {
+        const float ds = d_score[k];
+        gw = fmaf(ds, o1[(size_t)k * EMB + col], gw);
+        d_o1[(size_t)k * EMB + col] = ds * wj;
+    }
+    float gb = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) gb += d_score[k];
+    red[part][col] = gw; red2[threadIdx.x] = gb;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red2[threadIdx.x] += red2[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < EMB) g_w2[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) *g_b2 = red2[0];
+}
+
+// Keras-form Adam (model_trainer.py:131,273): eps outside the bias-corrected sqrt.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int n, float lr_t, float b1, float b2, float eps,
+                                              const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// graph plan kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_iota(int* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
+}
+// sorted keys -> segment offsets: ptr[k] = first position whose key >= k, ptr[n_seg] = n
+__global__ void k_seg_offsets(const int* __restrict__ keys, int n, int n_seg, int* __restrict__ ptr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        const int lo = i == 0 ? -1 : max(keys[i - 1], -1);
+        const int hi = i == n ? n_seg : min(keys[i], n_seg);
+        for (int k = lo + 1; k <= hi; ++k) ptr[k] = i;
+    }
+}
+__global__ void k_gather_edges(const int* __restrict__ perm, const int* __restrict__ other, const float* __restrict__ coef,
+                               int n, int* __restrict__ oth_out, float* __restrict__ coef_out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int e = perm[i];
+        oth_out[i] = other[e]; coef_out[i] = coef[e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static const int LIN_SMEM = (2 * 64 * LDW + 4 * 32 * LDW) * (int)sizeof(float);  // 69,632 B
+static const int MAX_GRID = 2048;
+
+static int launch_linear(bool transb, const LinArgs& a, hipStream_t st) {
+    if (a.n <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {  // 68 KB of dynamic LDS per block (gfx950 has 160 KB per CU)
+        HIPCHK(hipFuncSetAttribute((const void*)k_linear<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM));
+        HIPCHK(hipFuncSetAttribute((const void*)k_linear<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM));
+        attr_set = true;
+    }
+    const int grid = std::min(cdiv(a.n, 128), MAX_GRID);
+    if (transb) hipLaunchKernelGGL(k_linear<true>, dim3(grid), dim3(256), LIN_SMEM, st, a);
+    else hipLaunchKernelGGL(k_linear<false>, dim3(grid), dim3(256), LIN_SMEM, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+
+static LinArgs lin_fwd(const float* xa, const float* wa, const float* bias, int relu, float* y, int n) {
+    LinArgs a; memset(&a, 0, sizeof(a));
+    a.xa = xa; a.wa = wa; a.bias = bias; a.relu = relu; a.y = y; a.n = n;
+    return a;
+}
+static LinArgs lin_bwd(const float* dy, const float* ymask, const float* wa, float* dx, int beta, int n) {
+    LinArgs a; memset(&a, 0, sizeof(a));
+    a.xa = dy; a.ymask = ymask; a.write_back = ymask != nullptr; a.wa = wa; a.y = dx; a.beta_y = beta; a.n = n;
+    return a;
+}
+
+template <int MODE>
+static int launch_edge(bool recv_left, const EdgeArgs& a, int n_edges, hipStream_t st, int* grid_out = nullptr) {
+    if (grid_out) *grid_out = 0;
+    if (a.n_recv <= 0) return 0;
+    const double avg = (double)n_edges / (double)a.n_recv;
+    const int slots = avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
+    const int rpw = 4 / slots;
+    int grid = std::min(cdiv(cdiv(a.n_recv, rpw), 4), MAX_GRID);
+    if (MODE == 1) grid = std::min(grid, 1024);  // bounds the number of d w_edge partials
+#define EDGE_CASE(S, RL) hipLaunchKernelGGL((k_edge<S, RL, MODE>), dim3(grid), dim3(256), 0, st, a)
+    if (slots == 4) { if (recv_left) EDGE_CASE(4, true); else EDGE_CASE(4, false); }
+    else if (slots == 2) { if (recv_left) EDGE_CASE(2, true); else EDGE_CASE(2, false); }
+    else { if (recv_left) EDGE_CASE(1, true); else EDGE_CASE(1, false); }
+#undef EDGE_CASE
+    LAUNCHCHK();
+    if (grid_out) *grid_out = grid;
+    return 0;
+}
+static int edge_bwd_recv_grid(int n_recv, int n_edges) {
+    if (n_recv <= 0) return 0;
+    const double avg = (double)n_edges / (double)n_recv;
+    const int slots = avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
+    return std::min(std::min(cdiv(cdiv(n_recv, 4 / slots), 4), MAX_GRID), 1024);
+}
+
+// ---- workspace carving ------------------------------------------------------------------------------------------
+struct Acts {
+    float *E1c, *Xc, *PL1, *S1, *A1, *Z1c, *Xc2, *PL2;          // C rows
+    float *E1v, *Xv, *PR1, *PR2, *S2, *A2, *Z1v, *Xv2, *PR3;    // V rows
+    float *E1k, *Xk, *PL3, *S3, *A3, *Z1k, *Xk2, *O1;           // K rows
+};
+struct Work {
+    Acts a, g;            // activations and their gradients
+    float* partial;       // weight-gradient slabs
+    float* dw_partial[3]; // d w_edge partials per conv
+    float* emb_partial[3];
+    int dw_nblk[3];
+    int emb_nblk[3];
+    size_t total;
+};
+static inline size_t al4(size_t x) { return (x + 3) & ~(size_t)3; }
+#define EMB1_ROWS 512
+
+static size_t wg_slabs(const gcnn_dims* d) {  // total number of wgrad slabs over all 22 jobs
+    const int C = d->n_cons, V = d->n_vars, K = d->n_cuts;
+    const int bc = cdiv(C, WG_ROWS), bv = cdiv(V, WG_ROWS), bk = cdiv(K, WG_ROWS);
+    // jobs per row set (see gcnn_backward): cons 7, var 8, cut 7; 8 each leaves slack
+    return (size_t)bc * 8 + (size_t)bv * 8 + (size_t)bk * 8;
+}
+
+static void carve(const gcnn_dims* d, float* base, Work* w) {
+    const size_t C = d->n_cons, V = d->n_vars, K = d->n_cuts;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += al4(n); return p; };
+    for (int pass = 0; pass < 2; ++pass) {
+        Acts* t = pass ? &w->g : &w->a;
+        float** pc[] = {&t->E1c, &t->Xc, &t->PL1, &t->S1, &t->A1, &t->Z1c, &t->Xc2, &t->PL2};
+        float** pv[] = {&t->E1v, &t->Xv, &t->PR1, &t->PR2, &t->S2, &t->A2, &t->Z1v, &t->Xv2, &t->PR3};
+        float** pk[] = {&t->E1k, &t->Xk, &t->PL3, &t->S3, &t->A3, &t->Z1k, &t->Xk2, &t->O1};
+        for (auto p : pc) *p = take(C * EMB);
+        for (auto p : pv) *p = take(V * EMB);
+        for (auto p : pk) *p = take(K * EMB);
+    }
+    w->partial = take(wg_slabs(d) * WG_SLAB);
+    const int nrecv[3] = {d->n_cons, d->n_vars, d->n_cuts};
+    const int ne[3] = {d->n_cons_edges, d->n_cons_edges, d->n_cut_edges};
+    for (int i = 0; i < 3; ++i) {
+        w->dw_nblk[i] = edge_bwd_recv_grid(nrecv[i], ne[i]);
+        w->dw_partial[i] = take((size_t)w->dw_nblk[i] * EMB);
+    }
+    const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
+    const int femb[3] = {4, 14, 6};
+    for (int i = 0; i < 3; ++i) {
+        w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS);
+        w->emb_partial[i] = take((size_t)w->emb_nblk[i] * (femb[i] + 1) * EMB);
+    }
+    w->total = off;
+}
+
+extern "C" {
+
+int gcnn_abi_version(void) { return 1; }
+int gcnn_param_count(void) { return GCNN_N_PARAMS; }
+int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
+int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
+    layout_init();
+    if (index < 0 || index >= GCNN_N_PARAMS) return GCNN_E_BADARG;
+    if (offset) *offset = g_pinfo[index].off;
+    if (rows) *rows = g_pinfo[index].rows;
+    if (cols) *cols = g_pinfo[index].cols;
+    if (trainable) *trainable = g_pinfo[index].trainable;
+    return 0;
+}
+
+size_t gcnn_workspace_floats(const gcnn_dims* dims) {
+    if (!dims) return 0;
+    Work w; carve(dims, nullptr, &w);
+    return w.total;
+}
+
+// ---- graph plan -------------------------------------------------------------------------------------------------
+static size_t sort_temp_bytes(int n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr,
+                                       (int*)nullptr, n > 0 ? n : 1);
+    return (bytes + 255) & ~(size_t)255;
+}
+size_t gcnn_graph_temp_bytes(int32_t n_edges) {
+    const size_t e = ((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int) + 255) & ~(size_t)255;
+    return sort_temp_bytes(n_edges) + 3 * e;  // cub temp + iota + sorted keys + perm
+}
+
+int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left, int32_t n_var,
+                     int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth, float* v_coef,
+                     int32_t* l_perm, void* temp, size_t temp_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_edges < 0 || n_left < 0 || n_var < 0 || !l_ptr || !v_ptr) return GCNN_E_BADARG;
+    if (temp_bytes < gcnn_graph_temp_bytes(n_edges)) return GCNN_E_WORKSPACE;
+    if (n_edges == 0) {
+        HIPCHK(hipMemsetAsync(l_ptr, 0, (size_t)(n_left + 1) * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(v_ptr, 0, (size_t)(n_var + 1) * sizeof(int), st));
+        return 0;
+    }
+    if (!edge_inds || !edge_feats || !l_oth || !l_coef || !v_oth || !v_coef || !temp) return GCNN_E_BADARG;
+    const size_t e = ((size_t)n_edges * sizeof(int) + 255) & ~(size_t)255;
+    size_t cub_bytes = sort_temp_bytes(n_edges);
+    char* t = (char*)temp;
+    void* cub_tmp = t;
+    int* iota = (int*)(t + cub_bytes);
+    int* keys = (int*)(t + cub_bytes + e);
+    int* perm = (int*)(t + cub_bytes + 2 * e);
+    const int grid = std::min(cdiv(n_edges + 1, 256), 4096);
+    const int* left = edge_inds;
+    const int* var = edge_inds + n_edges;
+    hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, st, iota, n_edges);
+    LAUNCHCHK();
+    for (int side = 0; side < 2; ++side) {
+        const int* key_in = side == 0 ? left : var;
+        const int nseg = side == 0 ? n_left : n_var;
+        int bits = 1;
+        while ((1ll << bits) < (long long)nseg + 1 && bits < 31) ++bits;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, keys, (const int*)iota, perm, n_edges, 0,
+                                                  bits, st));
+        hipLaunchKernelGGL(k_seg_offsets, dim3(grid), dim3(256), 0, st, keys, n_edges, nseg, side == 0 ? l_ptr : v_ptr);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_gather_edges, dim3(grid), dim3(256), 0, st, perm, side == 0 ? var : left, edge_feats,
+                           n_edges, side == 0 ? l_oth : v_oth, side == 0 ? l_coef : v_coef);
+        LAUNCHCHK();
+        if (side == 0 && l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+// ---- standalone scatter-sum pass --------------------------------------------------------------------------------
+int gcnn_seg_sum_f32(const float* msg, const int32_t* seg_ptr, const int32_t* perm, int32_t n_recv, float* out,
+                     void* stream) {
+    if (n_recv < 0 || (n_recv > 0 && (!seg_ptr || !out))) return GCNN_E_BADARG;  // msg may be NULL when E == 0
+    if (n_recv == 0) return 0;
+    const int grid = std::min(cdiv(n_recv, 4), 8192);
+    if (perm) hipLaunchKernelGGL((k_seg_sum<4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, seg_ptr, perm, n_recv, out);
+    else hipLaunchKernelGGL((k_seg_sum<4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, seg_ptr, perm, n_recv, out);
+    LAUNCHCHK();
+    return 0;
+}
+int gcnn_seg_bcast_f32(const float* d_out, const int32_t* seg_ptr, const int32_t* perm, int32_t n_recv, float* d_msg,
+                       void* stream) {
+    if (n_recv < 0 || (n_recv > 0 && (!d_out || !seg_ptr))) return GCNN_E_BADARG;  // d_msg may be NULL when E == 0
+    if (n_recv == 0) return 0;
+    const int grid = std::min(cdiv(n_recv, 4), 8192);
+    if (perm) hipLaunchKernelGGL((k_seg_bcast<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, d_out, seg_ptr, perm, n_recv, d_msg);
+    else hipLaunchKernelGGL((k_seg_bcast<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, d_out, seg_ptr, perm, n_recv, d_msg);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---- per-op entry points (also the unit-test surface) -------------------------------------------------------------
+int gcnn_linear_fwd(const float* xa, const float* sa, const float* wa, const float* xb, const float* wb, const float* bias,
+                    const float* bd, const int32_t* seg_ptr, int32_t relu, float* y, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!xa || !wa || !y)) || (xb && !wb) || (bd && !seg_ptr)) return GCNN_E_BADARG;
+    LinArgs a = lin_fwd(xa, wa, bias, relu, y, n);
+    a.sa = sa; a.xb = xb; a.wb = xb ? wb : nullptr; a.bd = bd; a.seg_ptr = seg_ptr;
+    return launch_linear(false, a, (hipStream_t)stream);
+}
+int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float* so, float* dx, int32_t beta,
+                    const float* wb, float* dx2, int32_t beta2, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!dy || !wa || !dx)) || (dx2 && !wb)) return GCNN_E_BADARG;
+    LinArgs a = lin_bwd(dy, ymask, wa, dx, beta, n);
+    a.so = so; a.wb = dx2 ? wb : nullptr; a.y2 = dx2; a.beta_y2 = beta2;
+    return launch_linear(true, a, (hipStream_t)stream);
+}
+static EdgeArgs edge_args(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const float* p_own,
+                          const float* p_oth, const float* w_edge, const float* e_shift, const float* e_scale,
+                          const float* s1, const float* d_s, float* out, float* dw_partial, int n_own) {
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_own; e.p_oth = p_oth; e.w_edge = w_edge;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.d_s = d_s; e.out = out; e.dw_partial = dw_partial;
+    e.n_recv = n_own;
+    return e;
+}
+int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
+                       int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
+                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, void* stream) {
+    if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
+    if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
+    EdgeArgs e = edge_args(seg_ptr, oth, coef, p_recv, p_oth, w_edge, e_shift, e_scale, s1, nullptr, s_out, nullptr, n_recv);
+    return launch_edge<0>(recv_is_left != 0, e, n_edges, (hipStream_t)stream);
+}
+int32_t gcnn_conv_edge_bwd_partials(int32_t n_recv, int32_t n_edges) { return edge_bwd_recv_grid(n_recv, n_edges); }
+int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv,
+                            int32_t n_edges, int32_t recv_is_left, const float* p_recv, const float* p_oth,
+                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
+                            const float* d_s, float* d_p_recv, float* dw_partial, void* stream) {
+    if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
+    if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !d_s || !d_p_recv || !dw_partial)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
+    EdgeArgs e = edge_args(seg_ptr, oth, coef, p_recv, p_oth, w_edge, e_shift, e_scale, s1, d_s, d_p_recv, dw_partial, n_recv);
+    return launch_edge<1>(recv_is_left != 0, e, n_edges, (hipStream_t)stream);
+}
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send,
+                            int32_t n_edges, int32_t send_is_left, const float* p_send, const float* p_recv,
+                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
+                            const float* d_s, float* d_p_send, void* stream) {
+    if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
+    if (n_send > 0 && (!seg_ptr || !p_send || !w_edge || !e_shift || !e_scale || !s1 || !d_p_send)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !p_recv || !d_s)) return GCNN_E_BADARG;
+    EdgeArgs e = edge_args(seg_ptr, oth, coef, p_send, p_recv, w_edge, e_shift, e_scale, s1, d_s, d_p_send, nullptr, n_send);
+    return launch_edge<2>(send_is_left != 0, e, n_edges, (hipStream_t)stream);
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-203, 294-296)
+    int pbase;            // first parameter index of the block
+    const float* xl; const float* xv; int nl, nv, ne;
+    bool recv_left;
+    const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
+    float *PL, *PR, *S, *A, *Z1, *OUT;
+    float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV;
+};
+
+static int embed1_fwd(int f, const float* x, const float* p, int pb, float* y, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int grid = std::min(cdiv(n, 16), MAX_GRID);
+    const float *sh = p + poff(pb + E_SHIFT), *sc = p + poff(pb + E_SCALE), *w = p + poff(pb + E_W1), *b = p + poff(pb + E_B1);
+    if (f == 4) hipLaunchKernelGGL(k_embed1_fwd<4>, dim3(grid), dim3(256), 0, st, x, sh, sc, w, b, y, n);
+    else if (f == 14) hipLaunchKernelGGL(k_embed1_fwd<14>, dim3(grid), dim3(256), 0, st, x, sh, sc, w, b, y, n);
+    else hipLaunchKernelGGL(k_embed1_fwd<6>, dim3(grid), dim3(256), 0, st, x, sh, sc, w, b, y, n);
+    LAUNCHCHK();
+    return 0;
+}
+
+static int conv_forward(const float* p, const ConvIO& c, hipStream_t st) {
+    int rc;
+    const int nr = c.recv_left ? c.nl : c.nv;
+    const float* xrecv = c.recv_left ? c.xl : c.xv;
+    // K3/K4: projections (model.py:486-496)
+    LinArgs a = lin_fwd(c.xl, p + poff(c.pbase + C_WL), p + poff(c.pbase + C_BL), 0, c.PL, c.nl);
+    if ((rc = launch_linear(false, a, st))) return rc;
+    a = lin_fwd(c.xv, p + poff(c.pbase + C_WR), nullptr, 0, c.PR, c.nv);
+    if ((rc = launch_linear(false, a, st))) return rc;
+    // K5-K7+K9: fused edge pass
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
+    e.oth = c.recv_left ? c.g->l_oth : c.g->v_oth;
+    e.coef = c.recv_left ? c.g->l_coef : c.g->v_coef;
+    e.p_recv = c.recv_left ? c.PL : c.PR; e.p_oth = c.recv_left ? c.PR : c.PL;
+    e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
+    e.s1 = p + poff(c.pbase + C_S1); e.out = c.S; e.n_recv = nr;
+    if ((rc = launch_edge<0>(c.recv_left, e, c.ne, st))) return rc;
+    // K8 hoisted: A = S W_f + deg * b_f
+    a = lin_fwd(c.S, p + poff(c.pbase + C_WF), nullptr, 0, c.A, nr);
+    a.bd = p + poff(c.pbase + C_BF); a.seg_ptr = e.seg_ptr;
+    if ((rc = launch_linear(false, a, st))) return rc;
+    // K10+K11: relu([s2*A | x_recv] W1 + b1), relu(. W2 + b2)
+    a = lin_fwd(c.A, p + poff(c.pbase + C_W1), p + poff(c.pbase + C_B1), 1, c.Z1, nr);
+    a.sa = p + poff(c.pbase + C_S2); a.xb = xrecv; a.wb = p + poff(c.pbase + C_W1) + EMB * EMB;
+    if ((rc = launch_linear(false, a, st))) return rc;
+    a = lin_fwd(c.Z1, p + poff(c.pbase + C_W2), p + poff(c.pbase + C_B2), 1, c.OUT, nr);
+    return launch_linear(false, a, st);
+}
+
+static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
+    const Acts &A = w.a, &G = w.g;
+    cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv};
+    cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv};
+    cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2};
+}
+
+static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
+                        float* workspace, size_t workspace_floats) {
+    if (!d || !params || !cg || !kg) return GCNN_E_BADARG;
+    if (d->n_cons < 0 || d->n_vars < 0 || d->n_cuts < 0 || d->n_cons_edges < 0 || d->n_cut_edges < 0) return GCNN_E_BADARG;
+    if (!workspace || workspace_floats < gcnn_workspace_floats(d)) return GCNN_E_WORKSPACE;
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)params & 15)) return GCNN_E_BADARG;
+    return 0;
+}
+
+int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                 const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                 size_t workspace_floats, float* scores, void* stream) {
+    layout_init();
+    int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Work w; carve(d, workspace, &w);
+    const Acts& A = w.a;
+    // embeddings (model.py:287-291)
+    if ((rc = embed1_fwd(4, cons_feats, p, P_CONS, A.E1c, d->n_cons, st))) return rc;
+    if ((rc = embed1_fwd(14, var_feats, p, P_VAR, A.E1v, d->n_vars, st))) return rc;
+    if ((rc = embed1_fwd(6, cut_feats, p, P_CUT, A.E1k, d->n_cuts, st))) return rc;
+    LinArgs a = lin_fwd(A.E1c, p + poff(P_CONS + E_W2), p + poff(P_CONS + E_B2), 1, A.Xc, d->n_cons);
+    if ((rc = launch_linear(false, a, st))) return rc;
+    a = lin_fwd(A.E1v, p + poff(P_VAR + E_W2), p + poff(P_VAR + E_B2), 1, A.Xv, d->n_vars);
+    if ((rc = launch_linear(false, a, st))) return rc;
+    a = lin_fwd(A.E1k, p + poff(P_CUT + E_W2), p + poff(P_CUT + E_B2), 1, A.Xk, d->n_cuts);
+    if ((rc = launch_linear(false, a, st))) return rc;
+    // convolutions (model.py:294-296)
+    ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+    for (int i = 0; i < 3; ++i)
+        if ((rc = conv_forward(p, cv[i], st))) return rc;
+    // readout (model.py:299-300)
+    a = lin_fwd(A.Xk2, p + poff(P_OUT), p + poff(P_OUT + 1), 1, A.O1, d->n_cuts);
+    if ((rc = launch_linear(false, a, st))) return rc;
+    if (d->n_cuts > 0) {
+        if (!scores) return GCNN_E_BADARG;
+        hipLaunchKernelGGL(k_score, dim3(std::min(cdiv(d->n_cuts, 16), MAX_GRID)), dim3(256), 0, st, A.O1,
+                           p + poff(P_OUT + 2), p + poff(P_OUT + 3), scores, d->n_cuts);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+struct JobList {
+    WgArgs wg; RdArgs rd; int nslab;
+    int rdblk;
+};
+static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr, int n,
+                   float* gw, float* gb, float* gbd, float* partial) {
+    if (n <= 0) {  // empty input: gradients are exactly zero
+        return;
+    }
+    WgJob& j = jl.wg.job[jl.wg.njobs++];
+    const int nb = cdiv(n, WG_ROWS);
+    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
+    const float* src = partial + (size_t)jl.nslab * WG_SLAB;
+    jl.wg.nblocks += nb; jl.nslab += nb;
+    auto rd = [&](const float* s, float* dst, int len) {
+        RdJob& r = jl.rd.job[jl.rd.njobs++];
+        r.src = s; r.dst = dst; r.nparts = nb; r.stride = WG_SLAB; r.len = len; r.blk0 = jl.rdblk;
+        jl.rdblk += cdiv(len, EMB);
+    };
+    rd(src, gw, EMB * EMB);
+    if (gb) rd(src + EMB * EMB, gb, EMB);
+    if (gbd) rd(src + EMB * EMB + EMB, gbd, EMB);
+}
+static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int stride, int len) {
+    if (nparts <= 0) return;
+    RdJob& r = jl.rd.job[jl.rd.njobs++];
+    r.src = src; r.dst = dst; r.nparts = nparts; r.stride = stride; r.len = len; r.blk0 = jl.rdblk;
+    jl.rdblk += cdiv(len, EMB);
+}
+
+static int conv_backward(const float* p, float* grads, const ConvIO& c, const Work& w, int ci, int beta_xl, int beta_xv,
+                         JobList& jl, hipStream_t st) {
+    int rc;
+    const int nr = c.recv_left ? c.nl : c.nv;
+    const float* xrecv = c.recv_left ? c.xl : c.xv;
+    float* gxrecv = c.recv_left ? c.gXL : c.gXV;
+    int& beta_recv = c.recv_left ? beta_xl : beta_xv;
+    const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
+    // out = relu(Z1 W2 + b2): dZ1 = (dOut * mask) W2^T
+    LinArgs a = lin_bwd(c.gOUT, c.OUT, p + poff(c.pbase + C_W2), c.gZ1, 0, nr);
+    if ((rc = launch_linear(true, a, st))) return rc;
+    // Z1 = relu(s2*A W1a + xrecv W1b + b1): dA = s2 * dZ1pre W1a^T ; dxrecv (+)= dZ1pre W1b^T
+    a = lin_bwd(c.gZ1, c.Z1, p + poff(c.pbase + C_W1), c.gA, 0, nr);
+    a.so = p + poff(c.pbase + C_S2); a.wb = p + poff(c.pbase + C_W1) + EMB * EMB; a.y2 = gxrecv; a.beta_y2 = beta_recv;
+    beta_recv = 1;
+    if ((rc = launch_linear(true, a, st))) return rc;
+    // A = S Wf + deg bf: dS = dA Wf^T
+    a = lin_bwd(c.gA, nullptr, p + poff(c.pbase + C_WF), c.gS, 0, nr);
+    if ((rc = launch_linear(true, a, st))) return rc;
+    // edge pass gradients
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
+    e.s1 = p + poff(c.pbase + C_S1);
+    // (1) receiver-ordered: dP_recv[r] and d w_edge
+    e.seg_ptr = seg; e.oth = c.recv_left ? c.g->l_oth : c.g->v_oth; e.coef = c.recv_left ? c.g->l_coef : c.g->v_coef;
+    e.p_recv = c.recv_left ? c.PL : c.PR; e.p_oth = c.recv_left ? c.PR : c.PL;
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPL : c.gPR; e.dw_partial = w.dw_partial[ci]; e.n_recv = nr;
+    int g = 0;
+    if (edge_bwd_recv_grid(nr, c.ne) > w.dw_nblk[ci]) return GCNN_E_WORKSPACE;
+    if ((rc = launch_edge<1>(c.recv_left, e, c.ne, st, &g))) return rc;
+    add_rd(jl, w.dw_partial[ci], grads + poff(c.pbase + C_WE), g, EMB, EMB);
+    // (2) sender-ordered: dP_send[u] = sum over the sender's edges, gathering P_recv and dS rows
+    const int ns = c.recv_left ? c.nv : c.nl;
+    e.seg_ptr = c.recv_left ? c.g->v_ptr : c.g->l_ptr; e.oth = c.recv_left ? c.g->v_oth : c.g->l_oth;
+    e.coef = c.recv_left ? c.g->v_coef : c.g->l_coef;
+    e.p_recv = c.recv_left ? c.PR : c.PL;  /* segment owner = sender */
+    e.p_oth = c.recv_left ? c.PL : c.PR;   /* gathered = receiver rows */
+    e.out = c.recv_left ? c.gPR : c.gPL; e.dw_partial = nullptr; e.n_recv = ns;
+    // segment owner is the left node iff the receiver is the variable side
+    if ((rc = launch_edge<2>(!c.recv_left, e, c.ne, st))) return rc;
+    // projections: dXL (+)= dPL Wl^T ; dXV (+)= dPR Wr^T
+    a = lin_bwd(c.gPL, nullptr, p + poff(c.pbase + C_WL), c.gXL, beta_xl, c.nl);
+    if ((rc = launch_linear(true, a, st))) return rc;
+    a = lin_bwd(c.gPR, nullptr, p + poff(c.pbase + C_WR), c.gXV, beta_xv, c.nv);
+    if ((rc = launch_linear(true, a, st))) return rc;
+    // weight-gradient jobs (all read buffers that stay untouched until the grouped launch)
+    add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
+    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
+    add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
+    add_wg(jl, c.S, nullptr, c.gA, seg, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
+    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.nl, grads + poff(c.pbase + C_WL), grads + poff(c.pbase + C_BL), nullptr, w.partial);
+    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr, nullptr, w.partial);
+    return 0;
+}
+
+static int embed1_wgrad(int f, const float* x, const float* p, int pb, const float* dy, const float* yact, float* partial,
+                        int n, int nblk, hipStream_t st) {
+    if (n <= 0) return 0;
+    const float *sh = p + poff(pb + E_SHIFT), *sc = p + poff(pb + E_SCALE);
+    if (f == 4) hipLaunchKernelGGL(k_embed1_wgrad<4>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
+    else if (f == 14) hipLaunchKernelGGL(k_embed1_wgrad<14>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
+    else hipLaunchKernelGGL(k_embed1_wgrad<6>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
+    LAUNCHCHK();
+    return 0;
+}
+
+int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out, float* d_scores,
+                  void* stream) {
+    if (n < 0 || (n > 0 && (!scores || !targets))) return GCNN_E_BADARG;
+    if (n == 0) {
+        if (loss_out) HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+        return 0;
+    }
+    hipLaunchKernelGGL(k_mse, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, targets, scale, loss_out, d_scores, n);
+    LAUNCHCHK();
+    return 0;
+}
+
+int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                  size_t workspace_floats, const float* d_scores, float* grads, void* stream) {
+    layout_init();
+    int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
+    if (rc) return rc;
+    if (!grads || (d->n_cuts > 0 && !d_scores)) return GCNN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Work w; carve(d, workspace, &w);
+    const Acts &A = w.a, &G = w.g;
+    JobList jl; memset(&jl, 0, sizeof(jl)); jl.wg.partial = w.partial;
+
+    // every trainable gradient is (re)written below only if its inputs are non-empty: start from zero
+    HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
+    if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
+
+    // Dense(64->1) gradient (model.py:208)
+    hipLaunchKernelGGL(k_score_bwd, dim3(1), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
+                       grads + poff(P_OUT + 2), grads + poff(P_OUT + 3), d->n_cuts);
+    LAUNCHCHK();
+    LinArgs a = lin_bwd(G.O1, A.O1, p + poff(P_OUT), G.Xk2, 0, d->n_cuts);
+    if ((rc = launch_linear(true, a, st))) return rc;
+    add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
+
+    ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+    // first-writer bookkeeping of the accumulated node gradients: 0 = overwrite, 1 = accumulate
+    // conv3 (cut): recv=left(Xk): gXk first written by W1b; gXv2 written by Wr (first).
+    if ((rc = conv_backward(p, grads, cv[2], w, 2, /*beta_xl (gXk)*/ 0, /*beta_xv (gXv2)*/ 0, jl, st))) return rc;
+    // conv2 (var): recv=var(Xv): gXv first written by W1b; gXc2 written by Wl (first).
+    if ((rc = conv_backward(p, grads, cv[1], w, 1, /*beta_xl (gXc2)*/ 0, /*beta_xv (gXv)*/ 0, jl, st))) return rc;
+    // conv1 (cons): recv=left(Xc): gXc first written by W1b; gXv accumulates.
+    if ((rc = conv_backward(p, grads, cv[0], w, 0, /*beta_xl (gXc)*/ 0, /*beta_xv (gXv)*/ 1, jl, st))) return rc;
+
+    // embeddings, second layer: X = relu(E1 W2 + b2)
+    struct { const float* x; const float* e1; const float* xo; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
+        {cons_feats, A.E1c, A.Xc, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
+        {var_feats, A.E1v, A.Xv, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
+        {cut_feats, A.E1k, A.Xk, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
+    for (int i = 0; i < 3; ++i) {
+        a = lin_bwd(em[i].gx, em[i].xo, p + poff(em[i].pb + E_W2), em[i].ge1, 0, em[i].n);
+        if ((rc = launch_linear(true, a, st))) return rc;
+        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
+        if ((rc = embed1_wgrad(em[i].f, em[i].x, p, em[i].pb, em[i].ge1, em[i].e1, w.emb_partial[i], em[i].n, w.emb_nblk[i], st))) return rc;
+        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
+        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
+        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
+    }
+    if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
+    if (jl.wg.nblocks > 0) {
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(256), 0, st, jl.wg);
+        LAUNCHCHK();
+    }
+    if (jl.rdblk > 0) {
+        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
+int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1, float beta2,
+                   float eps, const float* grad_scale, void* stream) {
+    if (n < 0 || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
+                       lr_t, beta1, beta2, eps, grad_scale);
+    LAUNCHCHK();
+    return 0;
+}
+
+}  // extern "C"

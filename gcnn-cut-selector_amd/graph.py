@@ -1,0 +1,73 @@
+"""Device-side index structures for one bipartite edge set.
+
+The reference feeds `tf.gather` / `tf.scatter_nd` a raw COO list (/root/reference/model.py:564-569).  Here the COO
+list is turned ONCE per batch into receiver-sorted CSR in both orders (by left node and by variable), so that the
+scatter-sum and every gradient of the gathers run as atomic-free segmented sums (gcnn_graph_build in
+include/gcnn_hip.h)."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
+
+
+class BipartiteGraph:
+    """One edge set (constraint<->variable or cut<->variable) in by-left and by-variable CSR form, on the GPU.
+
+    edge_inds: [2,E] int32, row 0 = left (constraint/cut) id, row 1 = variable id (utils.py:110,234).
+    edge_feats: [E,1] or [E] fp32 raw coefficients.  Any edge order is accepted; ties keep input order."""
+
+    def __init__(self, edge_inds: torch.Tensor, edge_feats: torch.Tensor, n_left: int, n_var: int, validate=True,
+                 keep_perm=False):
+        if edge_inds.dim() != 2 or edge_inds.shape[0] != 2:
+            raise ValueError(f"edge index tensor must have shape [2,E], got {tuple(edge_inds.shape)}")
+        if edge_inds.dtype != torch.int32:
+            raise ValueError(f"edge index tensor must be int32, got {edge_inds.dtype}")
+        n_edges = edge_inds.shape[1]
+        edge_feats = edge_feats.reshape(-1)
+        if edge_feats.numel() != n_edges or edge_feats.dtype != torch.float32:
+            raise ValueError("edge features must be fp32 with one value per edge")
+        if not edge_inds.is_cuda:
+            raise ValueError("BipartiteGraph expects device tensors (GCNN.prepare moves host inputs)")
+        dev = edge_inds.device
+        edge_inds = edge_inds.contiguous()
+        edge_feats = edge_feats.contiguous()
+        if validate and n_edges > 0:
+            lo = int(edge_inds.min())
+            hi_l, hi_v = int(edge_inds[0].max()), int(edge_inds[1].max())
+            if lo < 0 or hi_l >= n_left or hi_v >= n_var:
+                raise ValueError(f"edge index out of range: min {lo}, max left {hi_l} (n={n_left}), max var {hi_v} (n={n_var})")
+        self.n_edges, self.n_left, self.n_var, self.device = n_edges, int(n_left), int(n_var), dev
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.l_ptr = torch.empty(n_left + 1, **i32)
+        self.v_ptr = torch.empty(n_var + 1, **i32)
+        self.l_oth = torch.empty(n_edges, **i32)
+        self.v_oth = torch.empty(n_edges, **i32)
+        self.l_coef = torch.empty(n_edges, **f32)
+        self.v_coef = torch.empty(n_edges, **f32)
+        self.l_perm = torch.empty(n_edges, **i32) if keep_perm else None
+        lib = _lib.lib()
+        temp_bytes = lib.gcnn_graph_temp_bytes(n_edges)
+        temp = torch.empty(temp_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gcnn_graph_build(_ptr(edge_inds), _ptr(edge_feats), n_edges, n_left, n_var,
+                                            _ptr(self.l_ptr), _ptr(self.l_oth), _ptr(self.l_coef), _ptr(self.v_ptr),
+                                            _ptr(self.v_oth), _ptr(self.v_coef), _ptr(self.l_perm), _ptr(temp),
+                                            temp_bytes, _stream(dev)), "gcnn_graph_build")
+        # keep the temp alive until the stream has consumed it
+        temp.record_stream(torch.cuda.current_stream(dev))
+        self.c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
+                            self.l_coef.data_ptr() if n_edges else 0, self.v_ptr.data_ptr(),
+                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0)

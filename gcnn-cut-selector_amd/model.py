@@ -1,0 +1,305 @@
+"""`GCNN` with the call surface of the reference's model (/root/reference/model.py), running on hand-written HIP.
+
+Surface mirrored (file:line in the reference):
+  GCNN()                                   model.py:164-226   no-arg constructor, attrs emb_size/cons_feats/...
+  model(inputs10, training) / model.call   model.py:257-300   -> flat fp32 scores, `.numpy()` works (model_evaluator.py:103)
+  save_state / restore_state               model.py:47-67     62 consecutive pickle.dump(np.ndarray) records
+  pretrain_init / pretrain / pretrain_next model.py:69-133    PreNorm fitting hooks (model_trainer.py:207-230)
+  variables / trainable_variables          model.py:215, model_trainer.py:272-273
+  input_signature                          model.py:218-226   kept as a description of dtypes/shapes
+All arithmetic happens in libgcnn_hip.so (include/gcnn_hip.h); torch only stores tensors and hosts the autograd node.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import BipartiteGraph, _ptr, _stream
+
+EMB = 64
+
+
+def _emb_spec(prefix, f):
+    return [(f"{prefix}_prenorm/shift", (f,), False), (f"{prefix}_prenorm/scale", (f,), False),
+            (f"{prefix}_emb_1/kernel", (f, EMB), True), (f"{prefix}_emb_1/bias", (EMB,), True),
+            (f"{prefix}_emb_2/kernel", (EMB, EMB), True), (f"{prefix}_emb_2/bias", (EMB,), True)]
+
+
+def _conv_spec(name):
+    return [(f"{name}_feat_left/kernel", (EMB, EMB), True), (f"{name}_feat_left/bias", (EMB,), True),
+            (f"{name}_feat_edge/kernel", (1, EMB), True), (f"{name}_feat_right/kernel", (EMB, EMB), True),
+            (f"{name}_final_prenorm/scale", (1,), False),
+            (f"{name}_feat_final/kernel", (EMB, EMB), True), (f"{name}_feat_final/bias", (EMB,), True),
+            (f"{name}_post_prenorm/scale", (1,), False),
+            (f"{name}_out_1/kernel", (2 * EMB, EMB), True), (f"{name}_out_1/bias", (EMB,), True),
+            (f"{name}_out_2/kernel", (EMB, EMB), True), (f"{name}_out_2/bias", (EMB,), True)]
+
+
+# Checkpoint order = Keras `Model.variables` of the reference (model.py:53-56, 215): tracked sub-layers in attribute
+# order, each Dense [kernel, bias], each PreNormLayer [shift, scale].  Inferred from Keras 2.7 semantics; not verifiable
+# here without TensorFlow (shapes make a wrong order fail loudly in restore_state).
+VARIABLE_SPEC = (_emb_spec("cons", 4)
+                 + [("cons_edge_prenorm/shift", (1,), False), ("cons_edge_prenorm/scale", (1,), False)]
+                 + _emb_spec("var", 14) + _emb_spec("cut", 6)
+                 + [("cut_edge_prenorm/shift", (1,), False), ("cut_edge_prenorm/scale", (1,), False)]
+                 + _conv_spec("cons_conv") + _conv_spec("var_conv") + _conv_spec("cut_conv")
+                 + [("out_1/kernel", (EMB, EMB), True), ("out_1/bias", (EMB,), True),
+                    ("out_2/kernel", (EMB, 1), True), ("out_2/bias", (1,), True)])
+
+
+class ScoreTensor(torch.Tensor):
+    """Device tensor whose `.numpy()` copies to the host, so the reference's `model(...).numpy()` call sites work."""
+
+    def numpy(self, *args, **kwargs):
+        return torch.Tensor.numpy(self.detach().cpu().as_subclass(torch.Tensor), *args, **kwargs)
+
+
+class Batch:
+    """A stacked mini-batch resident on the GPU: features + both CSR orders of both edge sets (GCNN.prepare)."""
+
+    def __init__(self, cons_feats, var_feats, cut_feats, cons_graph, cut_graph):
+        self.cons_feats, self.var_feats, self.cut_feats = cons_feats, var_feats, cut_feats
+        self.cons_graph, self.cut_graph = cons_graph, cut_graph
+        self.dims = _lib.Dims(cons_feats.shape[0], var_feats.shape[0], cut_feats.shape[0], cons_graph.n_edges,
+                              cut_graph.n_edges)
+        self.n_edges = cons_graph.n_edges + cut_graph.n_edges
+        self.device = cons_feats.device
+
+
+def _as_device(x, dtype, device):
+    if isinstance(x, torch.Tensor):
+        t = x.detach()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.dtype != dtype:
+        if dtype == torch.int32 and t.dtype in (torch.int64, torch.int16, torch.uint8, torch.int8):
+            t = t.to(torch.int32)
+        elif dtype == torch.float32 and t.dtype in (torch.float64, torch.float16, torch.bfloat16, torch.bool,
+                                                    torch.int64, torch.int32):
+            t = t.to(torch.float32)
+        else:
+            raise ValueError(f"expected {dtype}, got {t.dtype}")
+    return t.to(device, non_blocking=True).contiguous()
+
+
+class _GCNNFunction(torch.autograd.Function):
+    """Autograd node around gcnn_forward / gcnn_backward (the role tf.GradientTape plays in model_trainer.py:269-272)."""
+
+    @staticmethod
+    def forward(ctx, flat, model, batch):
+        ws = model._take_workspace(batch)
+        scores = model._forward_into(flat, batch, ws)
+        ctx.model, ctx.batch, ctx.ws = model, batch, ws
+        ctx.save_for_backward(flat)
+        return scores
+
+    @staticmethod
+    def backward(ctx, d_scores):
+        model, batch, ws = ctx.model, ctx.batch, ctx.ws
+        if ws is None:
+            raise RuntimeError("GCNN backward called twice on the same forward pass")
+        (flat,) = ctx.saved_tensors
+        grads = torch.empty_like(flat)
+        model._backward_into(flat, batch, ws, d_scores.contiguous().to(torch.float32), grads)
+        model._give_workspace(ws)
+        ctx.ws = None
+        return grads, None, None
+
+
+class GCNN:
+    """Bipartite GCNN cut scorer (the reference's `GCNN(BaseModel)`, model.py:136-300) on MI355X."""
+
+    def __init__(self, device=None, seed=None):
+        self.emb_size, self.cons_feats, self.edge_feats, self.var_feats, self.cut_feats = EMB, 4, 1, 14, 6
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.GcnnError("GCNN needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
+        self.device = torch.device(device)
+        layout, total = _lib.param_layout()
+        if len(layout) != len(VARIABLE_SPEC):
+            raise _lib.GcnnError("library / binding disagree on the number of model variables")
+        for (off, rows, cols, tr), (name, shape, trainable) in zip(layout, VARIABLE_SPEC):
+            if rows * cols != int(np.prod(shape)) or tr != trainable:
+                raise _lib.GcnnError(f"library / binding disagree on variable {name}")
+        self._layout, self._total = layout, total
+        self._flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._flat.requires_grad_(True)
+        mask = torch.zeros(total, dtype=torch.bool)
+        for (off, rows, cols, tr) in layout:
+            if tr:
+                mask[off:off + rows * cols] = True
+        self._trainable_mask = mask.to(self.device)
+        self.variables_topological_order = [name for name, _, _ in VARIABLE_SPEC]
+        self.input_signature = [(("float32", (None, 4)), ("int32", (2, None)), ("float32", (None, 1)),
+                                 ("float32", (None, 14)), ("float32", (None, 6)), ("int32", (2, None)),
+                                 ("float32", (None, 1)), ("int32", ()), ("int32", ()), ("int32", ())), ("bool", ())]
+        self._ws_pool = []
+        self._prenorm_state = None
+        self._init_weights(np.random.default_rng(seed))
+
+    # ---- variables ---------------------------------------------------------------------------------------------
+    def _init_weights(self, rng):
+        """Keras defaults of the reference (model.py:175, 334, 342): orthogonal kernels, zero biases, shift 0, scale 1."""
+        host = np.zeros(self._total, np.float32)
+        for (off, rows, cols, _), (name, shape, _) in zip(self._layout, VARIABLE_SPEC):
+            n = rows * cols
+            if name.endswith("/kernel"):
+                r, c = shape
+                q, tri = np.linalg.qr(rng.standard_normal((max(r, c), min(r, c))))
+                q = q * np.sign(np.diag(tri))
+                host[off:off + n] = (q if r >= c else q.T).astype(np.float32).reshape(-1)
+            elif name.endswith("/scale"):
+                host[off:off + n] = 1.0
+        with torch.no_grad():
+            self._flat.copy_(torch.from_numpy(host))
+
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        """The single flat fp32 buffer holding all 62 variables (leaf tensor; `.grad` is filled by backward)."""
+        return self._flat
+
+    @property
+    def variables(self):
+        out = []
+        for (off, rows, cols, _), (_, shape, _) in zip(self._layout, VARIABLE_SPEC):
+            out.append(self._flat.detach()[off:off + rows * cols].view(shape))
+        return out
+
+    @property
+    def trainable_variables(self):
+        return [v for v, (_, _, tr) in zip(self.variables, VARIABLE_SPEC) if tr]
+
+    def gradients(self, flat_grad=None):
+        """The 46 gradient views matching `trainable_variables` (model_trainer.py:272), from a flat gradient buffer."""
+        g = self._flat.grad if flat_grad is None else flat_grad
+        if g is None:
+            raise RuntimeError("no gradient has been computed yet")
+        return [g[off:off + rows * cols].view(shape) for (off, rows, cols, tr), (_, shape, _) in
+                zip(self._layout, VARIABLE_SPEC) if tr]
+
+    def get_variable(self, name):
+        return self.variables[self.variables_topological_order.index(name)]
+
+    def set_weights(self, arrays):
+        """Assign the 62 variables from arrays in checkpoint order (dict name->array also accepted)."""
+        if isinstance(arrays, dict):
+            arrays = [arrays[n] for n in self.variables_topological_order]
+        if len(arrays) != len(VARIABLE_SPEC):
+            raise ValueError(f"expected {len(VARIABLE_SPEC)} arrays, got {len(arrays)}")
+        host = self._flat.detach().cpu().numpy().copy()
+        for a, (off, rows, cols, _), (name, shape, _) in zip(arrays, self._layout, VARIABLE_SPEC):
+            a = np.asarray(a, dtype=np.float32)
+            if a.shape != tuple(shape):
+                raise ValueError(f"variable {name}: expected shape {tuple(shape)}, got {a.shape}")
+            host[off:off + rows * cols] = a.reshape(-1)
+        with torch.no_grad():
+            self._flat.copy_(torch.from_numpy(host))
+
+    def get_weights(self):
+        host = self._flat.detach().cpu().numpy()
+        return [host[off:off + rows * cols].reshape(shape).copy() for (off, rows, cols, _), (_, shape, _) in
+                zip(self._layout, VARIABLE_SPEC)]
+
+    def save_state(self, path: str):
+        """model.py:47-56: one pickle.dump(np.ndarray) per variable, no header."""
+        with open(path, "wb") as file:
+            for a in self.get_weights():
+                pickle.dump(a, file)
+
+    def restore_state(self, path: str):
+        """model.py:58-67."""
+        arrays = []
+        with open(path, "rb") as file:
+            for _ in VARIABLE_SPEC:
+                arrays.append(pickle.load(file))
+        self.set_weights(arrays)
+
+    # ---- inputs ------------------------------------------------------------------------------------------------
+    def prepare(self, inputs, validate=True) -> Batch:
+        """10-tuple of NumPy arrays / torch tensors (model.py:263-275) -> device-resident Batch with CSR plans."""
+        if isinstance(inputs, Batch):
+            return inputs
+        if len(inputs) != 10:
+            raise ValueError(f"expected the reference's 10-tuple input, got {len(inputs)} items")
+        c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts = inputs
+        dev = self.device
+        c, v, k = (_as_device(x, torch.float32, dev) for x in (c, v, k))
+        cei, kei = _as_device(cei, torch.int32, dev), _as_device(kei, torch.int32, dev)
+        cef, kef = _as_device(cef, torch.float32, dev), _as_device(kef, torch.float32, dev)
+        for name, t, f in (("cons_feats", c, 4), ("var_feats", v, 14), ("cut_feats", k, 6)):
+            if t.dim() != 2 or t.shape[1] != f:
+                raise ValueError(f"{name} must have shape [N,{f}], got {tuple(t.shape)}")
+        for name, total, t in (("n_cons", n_cons, c), ("n_vars", n_vars, v), ("n_cuts", n_cuts, k)):
+            if int(total) != t.shape[0]:
+                raise ValueError(f"{name}={int(total)} does not match the {t.shape[0]} feature rows")
+        return Batch(c, v, k, BipartiteGraph(cei, cef, c.shape[0], v.shape[0], validate),
+                     BipartiteGraph(kei, kef, k.shape[0], v.shape[0], validate))
+
+    # ---- workspaces --------------------------------------------------------------------------------------------
+    def _take_workspace(self, batch):
+        need = _lib.lib().gcnn_workspace_floats(C.byref(batch.dims))
+        best = None
+        for i, ws in enumerate(self._ws_pool):
+            if ws.numel() >= need and (best is None or ws.numel() < self._ws_pool[best].numel()):
+                best = i
+        if best is not None:
+            return self._ws_pool.pop(best)
+        try:
+            return torch.empty(max(need, 4), dtype=torch.float32, device=self.device)
+        except torch.OutOfMemoryError:
+            self._ws_pool.clear()
+            torch.cuda.empty_cache()
+            return torch.empty(max(need, 4), dtype=torch.float32, device=self.device)
+
+    def _give_workspace(self, ws):
+        self._ws_pool.append(ws)
+        if len(self._ws_pool) > 2:
+            self._ws_pool.sort(key=lambda t: t.numel())
+            self._ws_pool.pop(0)
+
+    # ---- forward / backward ------------------------------------------------------------------------------------
+    def _forward_into(self, flat, batch, ws):
+        scores = torch.empty(batch.dims.n_cuts, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gcnn_forward(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
+                                               _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
+                                               C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(scores),
+                                               _stream(self.device)), "gcnn_forward")
+        return scores
+
+    def _backward_into(self, flat, batch, ws, d_scores, grads):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gcnn_backward(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
+                                                _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
+                                                C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(d_scores),
+                                                _ptr(grads), _stream(self.device)), "gcnn_backward")
+
+    def call(self, inputs, training=False):
+        """GCNN.call (model.py:257-300): flat fp32 scores, one per candidate cut.  `training` is accepted and ignored
+        exactly like the reference (no dropout / batch-norm).  Differentiable w.r.t. `flat_parameters` under autograd."""
+        batch = self.prepare(inputs)
+        if torch.is_grad_enabled() and self._flat.requires_grad:
+            scores = _GCNNFunction.apply(self._flat, self, batch)
+        else:
+            ws = self._take_workspace(batch)
+            scores = self._forward_into(self._flat.detach(), batch, ws)
+            self._give_workspace(ws)
+        return scores.as_subclass(ScoreTensor)
+
+    def __call__(self, inputs, training=False):
+        return self.call(inputs, training)
+
+    def get_concrete_function(self):
+        """Counterpart of `tf.function(model.call).get_concrete_function()` (model_evaluator.py:310-311): an inference
+        callable `(state10, training) -> scores` with `.numpy()`."""
+        def get_improvements(state, training=False):
+            with torch.no_grad():
+                return self.call(state, training)
+        return get_improvements

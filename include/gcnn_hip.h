@@ -1,0 +1,135 @@
+/* gcnn_hip.h -- C ABI of libgcnn_hip.so: the MI355X (gfx950) implementation of the bipartite GCNN hot path of
+ * stefanvanberkum/gcnn-cut-selector.
+ *
+ * The reference has no native layer and no FFI: its hot path is Python calling TensorFlow ops
+ * (/root/reference/model.py).  Each entry point below therefore cites the reference *Python* interface whose
+ * arithmetic it replaces.  All pointers are DEVICE pointers unless marked "host"; all matrices are row-major fp32,
+ * indices int32; `stream` is a hipStream_t passed as void*.  Every function returns 0 on success, a negative
+ * GCNN_E_* code on bad arguments and a positive hipError_t on a HIP failure; no function allocates device memory
+ * (workspaces are passed in), synchronises the device or throws.
+ */
+#ifndef GCNN_HIP_H
+#define GCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCNN_EMB 64
+#define GCNN_N_PARAMS 62          /* arrays in a checkpoint, model.py:53-56 */
+#define GCNN_E_BADARG (-1)
+#define GCNN_E_WORKSPACE (-2)
+
+/* ---- parameter layout --------------------------------------------------------------------------------------
+ * All 62 model variables live in ONE flat fp32 buffer, in the reference's checkpoint order
+ * (model.py:53-56, 215; shapes model.py:174-208, 486-508), each tensor starting at a multiple of 4 floats.
+ * Gradients and Adam moments use the same layout. */
+int gcnn_abi_version(void);
+int gcnn_param_count(void);                                   /* 62 */
+int gcnn_param_total_floats(void);                            /* size of the flat buffer */
+int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable);
+
+/* ---- sizes ------------------------------------------------------------------------------------------------ */
+typedef struct gcnn_dims {
+    int32_t n_cons, n_vars, n_cuts;        /* TOTAL node counts of the stacked batch (model.py:273-275) */
+    int32_t n_cons_edges, n_cut_edges;     /* E1, E2 */
+} gcnn_dims;
+
+/* One edge set in both receiver orders (built by gcnn_graph_build): by-left CSR and by-variable CSR. */
+typedef struct gcnn_graph {
+    const int32_t* l_ptr;   /* [n_left+1]  segment offsets, edges grouped by left (constraint/cut) node */
+    const int32_t* l_oth;   /* [E]         variable index of each edge, by-left order */
+    const float*   l_coef;  /* [E]         raw edge feature, by-left order */
+    const int32_t* v_ptr;   /* [n_var+1]   segment offsets, edges grouped by variable node */
+    const int32_t* v_oth;   /* [E]         left index of each edge, by-variable order */
+    const float*   v_coef;  /* [E]         raw edge feature, by-variable order */
+} gcnn_graph;
+
+/* ---- graph plan: COO -> receiver-sorted CSR in both orders -------------------------------------------------
+ * Replaces nothing arithmetic in the reference; it is the index structure that lets tf.scatter_nd
+ * (model.py:568-569) and the gradients of tf.gather (model.py:564-565) run as atomic-free segmented sums.
+ * edge_inds is the reference's [2,E] int32 tensor (row 0 = left id, row 1 = variable id, utils.py:110,234);
+ * any edge order is accepted (stable sort => deterministic summation order). */
+size_t gcnn_graph_temp_bytes(int32_t n_edges);
+int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left,
+                     int32_t n_var, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
+                     float* v_coef, int32_t* l_perm /* optional [E]: by-left position -> input edge id */,
+                     void* temp, size_t temp_bytes, void* stream);
+
+/* ---- standalone scatter-sum pass (K9): tf.scatter_nd(updates=[E,64], indices, shape=[R,64]), model.py:568-569
+ * seg_ptr[R+1] are receiver-sorted segment offsets; perm (optional) maps sorted position -> row of `msg`
+ * (NULL when msg is already receiver-sorted).  out[r] = sum of the segment's rows, 0 for empty segments. */
+int gcnn_seg_sum_f32(const float* msg, const int32_t* seg_ptr, const int32_t* perm, int32_t n_recv, float* out,
+                     void* stream);
+/* its transpose (the gradient of the pass): d_msg[perm[i]] = d_out[recv(i)] */
+int gcnn_seg_bcast_f32(const float* d_out, const int32_t* seg_ptr, const int32_t* perm, int32_t n_recv,
+                       float* d_msg, void* stream);
+
+/* ---- node GEMMs on the fp32 MFMA: Keras Dense(64) layers, model.py:174-208, 486-508 ---------------------------
+ * forward:  y = act( (sa*xa) @ wa [+ xb @ wb] [+ bias] [+ deg (x) bd] ),  deg_r = seg_ptr[r+1]-seg_ptr[r]
+ *           (the deg term is the hoisted bias of feature_module_final, model.py:499-500 summed by :568).
+ *           xa, xb, y: [n,64]; wa, wb: [64,64] Keras (in,out) layout; sa: optional device scalar.
+ * backward: dy <- dy * (ymask > 0) in place when ymask != NULL, then
+ *           dx (=|+=) so * (dy @ wa^T)  and optionally  dx2 (=|+=) dy @ wb^T   (beta 0 = overwrite, 1 = accumulate) */
+int gcnn_linear_fwd(const float* xa, const float* sa, const float* wa, const float* xb, const float* wb,
+                    const float* bias, const float* bd, const int32_t* seg_ptr, int32_t relu, float* y, int32_t n,
+                    void* stream);
+int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float* so, float* dx, int32_t beta,
+                    const float* wb, float* dx2, int32_t beta2, int32_t n, void* stream);
+
+/* ---- fused edge pass of PartialGraphConvolution.call, model.py:563-569, with Dense(feature_module_final) hoisted --
+ * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * ((PL[l_e] + c_e*w_edge) + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
+ *           p_recv = projected table of the receiving side [n_recv,64], p_oth = the other side's table, gathered by
+ *           oth[e]; recv_is_left: receiver is the constraint/cut side (from_v=True, model.py:553-556).
+ * bwd_recv: d_p_recv[r] = sum_e dJ_e, dJ_e = s1*d_s[r]*[s1*J_e > 0]; dw_partial: [gcnn_conv_edge_bwd_partials(..)][64]
+ *           per-block partial sums of d w_edge = sum_e c_e dJ_e (reduce in order for the final gradient).
+ * bwd_send: segments grouped by the SENDING node: d_p_send[u] = sum_{e in seg(u)} s1*d_s[oth_e]*[s1*J_e > 0]. */
+int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
+                       int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
+                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, void* stream);
+int32_t gcnn_conv_edge_bwd_partials(int32_t n_recv, int32_t n_edges);
+int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv,
+                            int32_t n_edges, int32_t recv_is_left, const float* p_recv, const float* p_oth,
+                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
+                            const float* d_s, float* d_p_recv, float* dw_partial, void* stream);
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send,
+                            int32_t n_edges, int32_t send_is_left, const float* p_send, const float* p_recv,
+                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
+                            const float* d_s, float* d_p_send, void* stream);
+
+/* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
+ * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied
+ * inside, model.py:365-382).  workspace: gcnn_workspace_floats(dims) floats; activations needed by
+ * gcnn_backward are left there.  scores: [n_cuts] (model.py:300). */
+size_t gcnn_workspace_floats(const gcnn_dims* dims);
+int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
+                 const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
+                 float* workspace, size_t workspace_floats, float* scores, void* stream);
+
+/* ---- MSE head: MeanSquaredError on 1-D input, model_trainer.py:132,271 ----------------------------------------
+ * loss_out[0] = scale * sum_k (scores_k - targets_k)^2 ; d_scores_k = 2*scale*(scores_k - targets_k).
+ * scale = 1/n gives Keras' mean; data-parallel callers pass 1/global_cut_count.  loss_out / d_scores may be NULL. */
+int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out,
+                  float* d_scores, void* stream);
+
+/* ---- backward: the vector-Jacobian product tf.GradientTape computes for GCNN.call, model_trainer.py:269-272 ----
+ * d_scores: [n_cuts] gradient of the loss w.r.t. the scores.  Gradients w.r.t. the 46 trainable tensors are
+ * written to `grads` (flat layout; the whole buffer is zeroed first, non-trainable slots stay 0).  Must follow
+ * gcnn_forward on the same workspace, inputs and parameters. */
+int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
+                  const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
+                  float* workspace, size_t workspace_floats, const float* d_scores, float* grads, void* stream);
+
+/* ---- Keras-form Adam over the flat buffer: model_trainer.py:131,273 ------------------------------------------
+ * theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (host double).
+ * grad_scale (optional device scalar, may be NULL) multiplies every gradient first (data-parallel mean). */
+int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1,
+                   float beta2, float eps, const float* grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCNN_HIP_H */

@@ -1,0 +1,195 @@
+"""Whole-model parity (GPU): the HIP GCNN against the CPU oracle on identical inputs and weights.
+Tolerance (BASELINE.json north star): scores within 1e-4 absolute of the fp32/fp64 restatement; gradients within
+1e-4 relative to the largest entry of each tensor (fp32 with a different summation order)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gcnn_cut_selector_amd import synthetic  # noqa: E402
+from oracle import gcnn_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def _model(seed, dev):
+    from gcnn_cut_selector_amd.model import GCNN
+    params = O.randomize_params(O.init_params(seed, np.float32), seed + 1)
+    m = GCNN(device=dev)
+    m.set_weights([params[n] for n in O.PARAM_NAMES])
+    return m, params
+
+
+def _check_scores(m, params, state, atol=1e-4):
+    got = m(state, False).numpy()
+    want64 = O.scores({k: v.astype(np.float64) for k, v in params.items()}, state, torch.float64)
+    assert got.shape == want64.shape and got.dtype == np.float32
+    np.testing.assert_allclose(got, want64, rtol=1e-4, atol=atol)
+    return got
+
+
+def test_variable_spec_matches_oracle():
+    from gcnn_cut_selector_amd.model import VARIABLE_SPEC
+    assert [(n, tuple(s), t) for n, s, t in VARIABLE_SPEC] == [(n, tuple(s), t) for n, s, t in O.PARAM_SPEC]
+
+
+@pytest.mark.parametrize("problem,batch,scale", [("setcov", 2, 0.1), ("setcov", 4, 1.0), ("combauc", 8, 1.0),
+                                                 ("capfac", 2, 0.2), ("indset", 4, 1.0)])
+def test_forward_parity(dev, problem, batch, scale):
+    m, params = _model(1, dev)
+    state, _, _ = synthetic.make_batch(problem, batch, scale=scale)
+    _check_scores(m, params, state)
+
+
+def test_forward_known_answer_single_edge(dev):
+    """Same hand-computed case as tests/test_oracle.py::test_known_answer_single_edge: answer 16.25."""
+    from gcnn_cut_selector_amd.model import GCNN, VARIABLE_SPEC
+    arrays = []
+    for name, shape, _ in VARIABLE_SPEC:
+        if name.endswith("/kernel"):
+            w = np.zeros(shape, np.float32)
+            if shape == (128, 64):
+                w[:64] = np.eye(64); w[64:] = np.eye(64)
+            elif shape[0] == shape[1]:
+                w = np.eye(64, dtype=np.float32)
+            elif shape[1] == 1:
+                w[:] = 1.0
+            else:
+                w[0, 0] = 1.0
+            arrays.append(w)
+        elif name.endswith("/scale"):
+            arrays.append(np.ones(shape, np.float32))
+        else:
+            arrays.append(np.zeros(shape, np.float32))
+    m = GCNN(device=dev)
+    m.set_weights(arrays)
+    st = (np.array([[2.0, 0, 0, 0]]), np.array([[0], [0]]), np.array([[0.5]]), np.array([[3.0] + [0] * 13]),
+          np.array([[1.0, 0, 0, 0, 0, 0]]), np.array([[0], [0]]), np.array([[0.25]]), 1, 1, 1)
+    np.testing.assert_allclose(m(st, False).numpy(), [16.25], rtol=1e-6)
+
+
+def test_isolated_nodes_and_unsorted_edges(dev):
+    m, params = _model(2, dev)
+    rng = np.random.default_rng(0)
+    C, V, K = 37, 45, 9
+    cei = np.stack([rng.integers(0, C - 5, 300), rng.integers(0, V - 7, 300)])   # last rows/cols isolated
+    kei = np.stack([rng.integers(0, K - 1, 80), rng.integers(0, V, 80)])         # last cut has no edge
+    state = (rng.standard_normal((C, 4)), cei, rng.standard_normal((300, 1)), rng.standard_normal((V, 14)),
+             rng.standard_normal((K, 6)), kei, rng.standard_normal((80, 1)), C, V, K)
+    _check_scores(m, params, state)
+
+
+def test_empty_cases(dev):
+    m, params = _model(3, dev)
+    rng = np.random.default_rng(1)
+    z2 = np.zeros((2, 0), np.int32)
+    # no cuts at all -> empty score vector
+    st = (rng.standard_normal((4, 4)), np.array([[0, 1], [1, 0]]), rng.standard_normal((2, 1)),
+          rng.standard_normal((3, 14)), np.zeros((0, 6)), z2, np.zeros((0, 1)), 4, 3, 0)
+    assert m(st, False).numpy().shape == (0,)
+    # cuts but no cut edges and no constraint edges
+    st = (rng.standard_normal((4, 4)), z2, np.zeros((0, 1)), rng.standard_normal((3, 14)),
+          rng.standard_normal((5, 6)), z2, np.zeros((0, 1)), 4, 3, 5)
+    _check_scores(m, params, st)
+
+
+def test_input_validation(dev):
+    m, _ = _model(3, dev)
+    state, _, _ = synthetic.make_batch("setcov", 1, scale=0.1)
+    bad = list(state); bad[0] = bad[0][:, :3]
+    with pytest.raises(ValueError):
+        m(tuple(bad), False)
+    bad = list(state); bad[7] = state[7] + 1
+    with pytest.raises(ValueError):
+        m(tuple(bad), False)
+    bad = list(state); bad[1] = state[1].copy(); bad[1][1, 0] = state[8]
+    with pytest.raises(ValueError):
+        m(tuple(bad), False)
+
+
+def test_batching_invariance(dev):
+    """SURVEY section 4 invariant 1 on the HIP path."""
+    m, _ = _model(4, dev)
+    samples = [synthetic.make_sample("setcov", i, scale=0.2) for i in range(3)]
+    full = synthetic.stack_samples(samples)
+    batched = m(full[:7] + (int(full[7].sum()), int(full[8].sum()), int(full[9].sum())), False).numpy()
+    singles = []
+    for s in samples:
+        b = synthetic.stack_samples([s])
+        singles.append(m(b[:7] + (int(b[7][0]), int(b[8][0]), int(b[9][0])), False).numpy())
+    np.testing.assert_allclose(batched, np.concatenate(singles), rtol=1e-5, atol=1e-6)
+
+
+def test_edge_order_invariance(dev):
+    m, _ = _model(5, dev)
+    state, _, _ = synthetic.make_batch("combauc", 2)
+    rng = np.random.default_rng(0)
+    p1, p2 = rng.permutation(state[1].shape[1]), rng.permutation(state[5].shape[1])
+    shuffled = (state[0], state[1][:, p1], state[2][p1], state[3], state[4], state[5][:, p2], state[6][p2]) + state[7:]
+    np.testing.assert_allclose(m(state, False).numpy(), m(shuffled, False).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_forward_is_deterministic_and_training_flag_inert(dev):
+    m, _ = _model(6, dev)
+    state, _, _ = synthetic.make_batch("indset", 2)
+    a, b = m(state, False).numpy(), m(state, True).numpy()
+    assert np.array_equal(a, b)
+
+
+def _grad_check(m, params, state, y, rtol=2e-4):
+    pred = m(state, True)
+    loss = ((pred - torch.as_tensor(y, device=pred.device)) ** 2).mean()
+    m.flat_parameters.grad = None
+    loss.backward()
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    _, want_loss, want = O.loss_and_grads(p64, state, y, torch.float64)
+    assert abs(float(loss.detach()) - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    names = [n for n, _, t in O.PARAM_SPEC if t]
+    bad = []
+    for name, g in zip(names, m.gradients()):
+        g = g.cpu().numpy().astype(np.float64)
+        w = want[name]
+        err = np.abs(g - w).max()
+        ref = max(np.abs(w).max(), 1e-6)
+        if not err <= rtol * ref + 1e-7:
+            bad.append((name, err, ref))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("problem,batch,scale", [("setcov", 2, 0.1), ("setcov", 3, 1.0), ("combauc", 4, 1.0),
+                                                 ("capfac", 2, 0.2), ("indset", 3, 1.0)])
+def test_backward_parity(dev, problem, batch, scale):
+    m, params = _model(7, dev)
+    state, y, _ = synthetic.make_batch(problem, batch, scale=scale)
+    _grad_check(m, params, state, y)
+
+
+def test_backward_isolated_and_unsorted(dev):
+    m, params = _model(8, dev)
+    rng = np.random.default_rng(3)
+    C, V, K = 37, 45, 9
+    cei = np.stack([rng.integers(0, C - 5, 300), rng.integers(0, V - 7, 300)])
+    kei = np.stack([rng.integers(0, K - 1, 80), rng.integers(0, V, 80)])
+    state = (rng.standard_normal((C, 4)), cei, rng.standard_normal((300, 1)), rng.standard_normal((V, 14)),
+             rng.standard_normal((K, 6)), kei, rng.standard_normal((80, 1)), C, V, K)
+    _grad_check(m, params, state, rng.uniform(0, 0.1, K))
+
+
+def test_save_restore_roundtrip(dev, tmp_path):
+    from gcnn_cut_selector_amd.model import GCNN
+    m, _ = _model(9, dev)
+    path = str(tmp_path / "best_params.pkl")
+    m.save_state(path)
+    m2 = GCNN(device=dev)
+    m2.restore_state(path)
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        assert np.array_equal(a, b)
+    import pickle
+    with open(path, "rb") as f:  # the reference's format: 62 bare pickled ndarrays (model.py:53-56)
+        arrs = [pickle.load(f) for _ in range(62)]
+    assert [a.shape for a in arrs] == [tuple(s) for _, s, _ in O.PARAM_SPEC]
