@@ -7,6 +7,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch ships its own libamdhip64; loading ours first
+#                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")
 ABI_VERSION = 1
 

@@ -1,0 +1,173 @@
+"""Training-step counterpart of the reference's `model_trainer.py` for the HIP GCNN.
+
+Mirrors (file:line in /root/reference):
+  process(model, dataloader, fractions, loss_fn, optimizer)  model_trainer.py:239-316  -> process()
+  pretrain(model, dataloader)                                 model_trainer.py:194-236  -> pretrain()
+  MeanSquaredError / Adam(learning_rate=lambda: lr)           model_trainer.py:131-132  -> mse_loss() / Adam
+  ranking-prefix accuracy                                     model_trainer.py:280-302  -> ranking_fraction()
+`train_step` is the fused fast path (no autograd graph): forward -> MSE head -> backward -> [RCCL all-reduce of ONE flat
+gradient buffer] -> Keras-form Adam, all on the current HIP stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import _ptr, _stream
+from .model import GCNN, Batch
+
+
+def mse_loss(scores: torch.Tensor, targets: torch.Tensor, scale: float | None = None, want_grad=True):
+    """Keras `MeanSquaredError` on 1-D inputs (model_trainer.py:132,271).  Returns (loss[1], d_scores|None)."""
+    n = scores.numel()
+    scale = (1.0 / n if n else 0.0) if scale is None else scale
+    loss = torch.empty(1, dtype=torch.float32, device=scores.device)
+    d = torch.empty_like(scores, memory_format=torch.contiguous_format) if want_grad else None
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.lib().gcnn_mse_loss(_ptr(scores), _ptr(targets), n, scale, _ptr(loss), _ptr(d),
+                                            _stream(scores.device)), "gcnn_mse_loss")
+    return loss, d
+
+
+class Adam:
+    """Keras-2.7 Adam (model_trainer.py:131): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps), eps=1e-7.
+    One fused kernel over the model's flat parameter buffer.  `learning_rate` may be a float or a zero-arg callable
+    (the reference passes `lambda: lr` so the plateau schedule can change it)."""
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
+        self.iterations = 0
+        self.m = self.v = None
+
+    def _lr(self):
+        return float(self.learning_rate() if callable(self.learning_rate) else self.learning_rate)
+
+    def apply_flat(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None):
+        flat = model.flat_parameters.detach()
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self._lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        with torch.cuda.device(flat.device):
+            _lib.check(_lib.lib().gcnn_adam_step(_ptr(flat), _ptr(flat_grad), _ptr(self.m), _ptr(self.v), flat.numel(),
+                                                 lr_t, self.beta_1, self.beta_2, self.epsilon, _ptr(grad_scale),
+                                                 _stream(flat.device)), "gcnn_adam_step")
+
+    def apply_gradients(self, model: GCNN):
+        """After `loss.backward()`: update from `model.flat_parameters.grad` (the reference's
+        `optimizer.apply_gradients(zip(grads, model.trainable_variables))`, model_trainer.py:273)."""
+        g = model.flat_parameters.grad
+        if g is None:
+            raise RuntimeError("no gradients: call loss.backward() first")
+        self.apply_flat(model, g)
+
+
+class TrainState:
+    """Buffers reused across steps by `train_step` (flat gradient + the data-parallel count slot)."""
+
+    def __init__(self, model: GCNN):
+        n = model.flat_parameters.numel()
+        # [gradients | local cut count | pad]: ONE buffer => ONE all-reduce per step
+        self.buf = torch.zeros(n + 4, dtype=torch.float32, device=model.device)
+        self.grads = self.buf[:n]
+        self.count = self.buf[n:n + 1]
+        self.inv_count = torch.ones(1, dtype=torch.float32, device=model.device)
+
+
+def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam | None, state: TrainState,
+               process_group=None):
+    """One training step on a prepared batch: forward + MSE + backward (+ all-reduce) (+ Adam).  Returns (loss, scores).
+
+    Single GPU: loss = mean over this batch's cuts (model_trainer.py:271).  Data parallel (`process_group` given): each
+    rank back-propagates the local SUM of squared errors; gradients and cut counts are summed with one RCCL all-reduce
+    and Adam divides by the global cut count -- the mean over ALL cuts of the global batch, not a mean of per-rank means."""
+    flat = model.flat_parameters.detach()
+    ws = model._take_workspace(batch)
+    scores = model._forward_into(flat, batch, ws)
+    n_cuts = batch.dims.n_cuts
+    if process_group is None:
+        loss, d_scores = mse_loss(scores, targets, 1.0 / max(n_cuts, 1))
+        model._backward_into(flat, batch, ws, d_scores, state.grads)
+        model._give_workspace(ws)
+        if optimizer is not None:
+            optimizer.apply_flat(model, state.grads)
+        return loss, scores
+    import torch.distributed as dist
+    loss, d_scores = mse_loss(scores, targets, 1.0)  # local SUM of squared errors
+    model._backward_into(flat, batch, ws, d_scores, state.grads)
+    model._give_workspace(ws)
+    state.count.fill_(float(n_cuts))
+    dist.all_reduce(state.buf, op=dist.ReduceOp.SUM, group=process_group)
+    torch.reciprocal(state.count, out=state.inv_count)
+    if optimizer is not None:
+        optimizer.apply_flat(model, state.grads, grad_scale=state.inv_count)
+    return loss, scores
+
+
+def ranking_fraction(pred: np.ndarray, true: np.ndarray) -> float:
+    """model_trainer.py:288-301: length of the ranking prefix on which prediction and truth agree, over #cuts.
+    Python's `sorted(..., reverse=True)` is stable, i.e. ties keep index order: a stable argsort of the negated key."""
+    pr = np.argsort(-np.asarray(pred), kind="stable")
+    tr = np.argsort(-np.asarray(true), kind="stable")
+    diff = pr != tr
+    return (int(np.argmax(diff)) if diff.any() else len(pr)) / len(pr)
+
+
+def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | None = None):
+    """Counterpart of model_trainer.process (model_trainer.py:239-316).  `dataloader` yields the 11-tuples of
+    `utils.load_batch` (per-sample count vectors + improvements).  Returns (cut-weighted mean loss, accuracy per fraction)."""
+    mean_loss, mean_acc = 0.0, np.zeros(len(fractions))
+    n_samples = cut_count = 0
+    state = TrainState(model) if optimizer is not None else None
+    for batch in dataloader:
+        (c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts, improvements) = batch
+        n_cuts = np.asarray(n_cuts).reshape(-1)
+        inputs = (c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)), int(n_cuts.sum()))
+        try:
+            prepared = model.prepare(inputs)
+            y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(model.device)
+            if optimizer is not None:
+                loss, predictions = train_step(model, prepared, y, optimizer, state)
+            else:
+                with torch.no_grad():
+                    predictions = model(prepared, False)
+                loss, _ = mse_loss(predictions, y, want_grad=False)
+            pred, true = predictions.detach().cpu().numpy(), np.asarray(improvements)
+            acc = np.zeros(len(fractions))
+            start = 0
+            for nk in n_cuts:
+                frac = ranking_fraction(pred[start:start + nk], true[start:start + nk])
+                acc += frac >= fractions
+                start += nk
+            total = int(n_cuts.sum())
+            mean_loss += float(loss) * total
+            mean_acc += acc
+            n_samples += len(n_cuts)
+            cut_count += total
+        except torch.OutOfMemoryError:  # the reference skips batches that exhaust memory (model_trainer.py:308-311)
+            print("WARNING: batch skipped.")
+    return mean_loss / max(cut_count, 1), mean_acc / max(n_samples, 1)
+
+
+def pretrain(model: GCNN, dataloader):
+    """Counterpart of model_trainer.pretrain (model_trainer.py:194-236): fit PreNorm layers one at a time."""
+    model.pretrain_init()
+    i = 0
+    while True:
+        for batch in dataloader:
+            inputs = tuple(batch[:7]) + (int(np.sum(batch[7])), int(np.sum(batch[8])), int(np.sum(batch[9])))
+            try:
+                if not model.pretrain(inputs, True):
+                    break
+            except torch.OutOfMemoryError:
+                print("WARNING: batch skipped.")
+        if model.pretrain_next() is None:
+            break
+        i += 1
+    return i
