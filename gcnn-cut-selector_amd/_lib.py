@@ -44,7 +44,6 @@ SIGNATURES = {
     "gcnn_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "gcnn_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gcnn_conv_edge_bwd_partials": (_I, [_I, _I]),
     "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcnn_workspace_floats": (_Z, [_DP]),

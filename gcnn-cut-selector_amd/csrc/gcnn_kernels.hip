@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void k_embed1_wgrad(const float* __restrict__ 
     for (int f = 0; f <= F; ++f) acc[f] = 0.f;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(n, r0 + rows_per_block);
+#pragma unroll 4
     for (int r = r0 + part; r < r1; r += 4) {
         float d = dy[(size_t)r * EMB + col];
         d = yact[(size_t)r * EMB + col] > 0.f ? d : 0.f;
@@ -309,6 +310,186 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Fused row chains.  Every node-side layer of the model is row-local (a 16-row tile of a [N,64] matrix goes through
+// a sequence of 64x64 products with element-wise epilogues), so a whole sequence -- e.g. S -> A -> Z1 -> X' -> PL'
+// of one PartialGraphConvolution (model.py:498-508, 570-573) or its gradient -- runs in ONE launch: each wave owns
+// 16-row tiles, keeps the running tile in LDS (2 tiles per wave), reads every weight of the chain from LDS
+// (staged once per block) and stores only the tensors the backward pass / the next edge pass need.
+// MFMA: v_mfma_f32_16x16x4_f32, 4 independent accumulators (the four 16-column tiles of the output).  The k index is
+// split across the four 16-lane groups (group g takes k in [16g, 16g+16)), so the 64 products of a dot product are
+// added in the order 0,16,32,48,1,17,... (exact fp32 FMA chain).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#define CH_MAX_STAGES 6
+#define CH_MAX_W 5
+#define CH_TILE (16 * LDW)
+enum { CH_GEMM = 0, CH_EMBED1 = 1, CH_SCORE = 2 };
+struct ChStage {
+    int type;
+    // A operand: global rows (loaded into LDS tile `ta`) or, when in_a == nullptr, whatever tile `ta` already holds
+    const float* in_a; const float* sa; int ta; int wa;
+    // optional second product accumulated into the same output: always from global, via tile `tb`
+    const float* in_b; int tb; int wb;
+    int transb;                       // 0: x @ W (forward), 1: x @ W^T (input gradients)
+    // epilogue, in this order: *so, +bias, +deg*bd, +add, relu, *(mask > 0)
+    const float* so; const float* bias; const float* bd; const int* seg_ptr; const float* add; const float* mask;
+    int relu;
+    float* out; int tout;             // global store (optional) and the LDS tile that keeps the result
+    // CH_EMBED1: x_raw [N,F], PreNorm shift/scale [F], kernel [F,64] (global), bias via `bias`
+    const float* x_raw; const float* shift; const float* scale; const float* w1; int nfeat;
+    // CH_SCORE: out[r] = tile(ta)[r] . w1[0:64] + *bias
+};
+struct ChArgs { int n; int nstage; int nw; const float* w[CH_MAX_W]; ChStage st[CH_MAX_STAGES]; };
+
+__device__ __forceinline__ void ch_load_tile(float* t, const float* __restrict__ x, int row0, int n, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = i * 4 + (lane >> 4), c = (lane & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < n) v = *(const float4*)(x + (size_t)(row0 + r) * EMB + c);
+        *(float4*)(t + r * LDW + c) = v;
+    }
+}
+
+template <bool TRANSB>
+__device__ __forceinline__ void ch_gemm(const float* t, const float* wl, float sa, f32x4 (&acc)[4], int lane) {
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 a4 = *(const float4*)(t + r * LDW + 16 * g + 4 * q);
+        const float av[4] = {a4.x * sa, a4.y * sa, a4.z * sa, a4.w * sa};
+        if (TRANSB) {
+            float bv[4][4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const float4 b4 = *(const float4*)(wl + (ct * 16 + r) * LDW + 16 * g + 4 * q);
+                bv[ct][0] = b4.x; bv[ct][1] = b4.y; bv[ct][2] = b4.z; bv[ct][3] = b4.w;
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av[tt], bv[ct][tt], acc[ct]);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int k = 16 * g + 4 * q + tt;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av[tt], wl[k * LDW + ct * 16 + r], acc[ct]);
+            }
+        }
+    }
+}
+
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_chain(ChArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tiles = smem + a.nw * 64 * LDW + wv * 2 * CH_TILE;
+    // stage the chain's weights: [nw][64][LDW]
+    for (int idx = threadIdx.x; idx < a.nw * 1024; idx += NWAVES * 64) {
+        const int wi = idx >> 10, r = (idx >> 4) & 63, c = (idx & 15) * 4;
+        *(float4*)(smem + wi * 64 * LDW + r * LDW + c) = *(const float4*)(a.w[wi] + r * EMB + c);
+    }
+    __syncthreads();
+
+    const int ntile = (a.n + 15) >> 4;
+    for (int tile = blockIdx.x * NWAVES + wv; tile < ntile; tile += gridDim.x * NWAVES) {
+        const int row0 = tile * 16;
+        for (int s = 0; s < a.nstage; ++s) {
+            const ChStage& st = a.st[s];
+            float* tout = tiles + st.tout * CH_TILE;
+            if (st.type == CH_SCORE) {
+                const float* t = tiles + st.ta * CH_TILE;
+                const int r = lane >> 2, q = lane & 3;
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = *(const float4*)(t + r * LDW + q * 16 + i * 4);
+                    const float4 w = *(const float4*)(st.w1 + q * 16 + i * 4);
+                    sum = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, sum))));
+                }
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+                if (q == 0 && row0 + r < a.n) st.out[row0 + r] = sum + *st.bias;
+                continue;
+            }
+            if (st.type == CH_EMBED1) {
+                // relu(((x + shift) * scale) @ W1 + b1): lane = (row, 16-column group), K <= 16 on the VALU
+                const int r = lane & 15, cg = (lane >> 4) * 16;
+                float accv[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) accv[c] = 0.f;
+                const bool ok = row0 + r < a.n;
+                for (int f = 0; f < st.nfeat; ++f) {
+                    const float xv = ok ? (st.x_raw[(size_t)(row0 + r) * st.nfeat + f] + st.shift[f]) * st.scale[f] : 0.f;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float4 w = *(const float4*)(st.w1 + f * EMB + cg + c4 * 4);
+                        accv[c4 * 4 + 0] = fmaf(xv, w.x, accv[c4 * 4 + 0]); accv[c4 * 4 + 1] = fmaf(xv, w.y, accv[c4 * 4 + 1]);
+                        accv[c4 * 4 + 2] = fmaf(xv, w.z, accv[c4 * 4 + 2]); accv[c4 * 4 + 3] = fmaf(xv, w.w, accv[c4 * 4 + 3]);
+                    }
+                }
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+                    *(float4*)(tout + r * LDW + cg + c4 * 4) = make_float4(accv[c4 * 4], accv[c4 * 4 + 1], accv[c4 * 4 + 2], accv[c4 * 4 + 3]);
+            } else {
+                f32x4 acc[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                float* ta = tiles + st.ta * CH_TILE;
+                if (st.in_a) ch_load_tile(ta, st.in_a, row0, a.n, lane);
+                const float sa = st.sa ? *st.sa : 1.f;
+                const float* wl = smem + st.wa * 64 * LDW;
+                if (st.transb) ch_gemm<true>(ta, wl, sa, acc, lane); else ch_gemm<false>(ta, wl, sa, acc, lane);
+                if (st.in_b) {
+                    float* tb = tiles + st.tb * CH_TILE;
+                    ch_load_tile(tb, st.in_b, row0, a.n, lane);
+                    const float* wl2 = smem + st.wb * 64 * LDW;
+                    if (st.transb) ch_gemm<true>(tb, wl2, 1.f, acc, lane); else ch_gemm<false>(tb, wl2, 1.f, acc, lane);
+                }
+                const float so = st.so ? *st.so : 1.f;
+                const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tout[(4 * g + i) * LDW + ct * 16 + j] = acc[ct][i] * so;
+            }
+            // row pass over the output tile: full 256-B lines, 16 B per lane
+            const int c = (lane & 15) * 4;
+            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), bd = bias;
+            if (st.bias) bias = *(const float4*)(st.bias + c);
+            if (st.bd) bd = *(const float4*)(st.bd + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = i * 4 + (lane >> 4), gr = row0 + r;
+                float4 v = *(const float4*)(tout + r * LDW + c);
+                const bool ok = gr < a.n;
+                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+                if (st.bd && ok) {
+                    const float deg = (float)(st.seg_ptr[gr + 1] - st.seg_ptr[gr]);
+                    v.x = fmaf(deg, bd.x, v.x); v.y = fmaf(deg, bd.y, v.y); v.z = fmaf(deg, bd.z, v.z); v.w = fmaf(deg, bd.w, v.w);
+                }
+                if (st.add && ok) {
+                    const float4 o = *(const float4*)(st.add + (size_t)gr * EMB + c);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (st.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (st.mask && ok) {
+                    const float4 m = *(const float4*)(st.mask + (size_t)gr * EMB + c);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4*)(tout + r * LDW + c) = v;
+                if (st.out && ok) *(float4*)(st.out + (size_t)gr * EMB + c) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
 // Grouped launch: one job per (X, D) pair, one block per 256-row chunk of a job.  Wave w owns the 32x32 quadrant
 // (w>>1, w&1) of G; rows are the MFMA k dimension.  Per-block partial slab [64*64 + 64 + 64] floats; summed in a
@@ -317,7 +498,7 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
 #define WG_ROWS 256
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 24
-struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; int n; int blk0; int slab0; };
+struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float* d2; int n; int blk0; int slab0; };
 struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
@@ -365,10 +546,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
             const int r = part * 16 + s;
             const float dv = ds[r * LDW + col];
             cs += dv;
-            if (jb.seg_ptr) {
-                const int gr = row0 + r;
+            const int gr = row0 + r;
+            if (jb.seg_ptr) {        // second column sum: degree-weighted (gradient of the hoisted b_f)
                 const float deg = gr < rend ? (float)(jb.seg_ptr[gr + 1] - jb.seg_ptr[gr]) : 0.f;
                 cds = fmaf(deg, dv, cds);
+            } else if (jb.d2) {      // ... or the plain column sum of a second matrix (Q -> d w_edge)
+                cds += gr < rend ? jb.d2[(size_t)gr * EMB + col] : 0.f;
             }
         }
     }
@@ -397,10 +580,18 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
     const int chunk = blockIdx.x - jb.blk0;
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int e = chunk * EMB + col;
-    float s = 0.f;
-    if (e < jb.len)
-        for (int p = part; p < jb.nparts; p += 4) s += jb.src[(size_t)p * jb.stride + e];
-    red[part][col] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < jb.len) {
+        const float* src = jb.src + e;
+        int p = part;
+        for (; p + 12 < jb.nparts; p += 16) {  // 4 loads in flight per thread; the order of the adds is fixed
+            const float v0 = src[(size_t)p * jb.stride], v1 = src[(size_t)(p + 4) * jb.stride];
+            const float v2 = src[(size_t)(p + 8) * jb.stride], v3 = src[(size_t)(p + 12) * jb.stride];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; p < jb.nparts; p += 4) s0 += src[(size_t)p * jb.stride];
+    }
+    red[part][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (part == 0 && e < jb.len) jb.dst[e] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
@@ -420,7 +611,7 @@ struct EdgeArgs {
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
     const float* d_s;                              // backward only: dS [R,64] (recv pass) or gathered (send pass)
     float* out;                                    // S (fwd) / dP_recv / dP_send
-    float* dw_partial;                             // backward recv pass: per-block [64] partial of d w_edge
+    float* dw_partial;                             // backward recv pass: Q [R,64], per-receiver partial of d w_edge
     int n_recv;
 };
 
@@ -440,12 +631,10 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
 template <int SLOTS, bool OWNER_LEFT, int MODE>
 __global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
-    __shared__ float dwred[4][EMB];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, ch = (gl & 15) * 4;
     const float4 w = *(const float4*)(a.w_edge + ch);
     const float esh = *a.e_shift, esc = *a.e_scale, s1 = *a.s1;
-    float4 dw = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int nwork = (a.n_recv + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
@@ -455,7 +644,7 @@ __global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
             const float4 pown = *(const float4*)(a.p_recv + (size_t)r * EMB + ch);
             float4 down = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == 1) down = *(const float4*)(a.d_s + (size_t)r * EMB + ch);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
             for (int base = beg; base < end; base += G) {
                 const int e = base + gl;
                 int o = 0; float c = 0.f;
@@ -507,17 +696,11 @@ __global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
             }
             acc = slot_reduce<SLOTS>(acc);
             if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = acc;
+            if (MODE == 1) {  // Q[r] = sum_e c_e dJ_e: this receiver's share of d w_edge, column-summed by k_wgrad
+                dw = slot_reduce<SLOTS>(dw);
+                if (slot == 0) *(float4*)(a.dw_partial + (size_t)r * EMB + ch) = dw;
+            }
         }
-    }
-    if (MODE == 1) {
-        // lanes with equal channel group (lane & 15) hold partials of the same 4 channels: 4 per wave, 4 waves
-        dw.x += __shfl_xor(dw.x, 16); dw.y += __shfl_xor(dw.y, 16); dw.z += __shfl_xor(dw.z, 16); dw.w += __shfl_xor(dw.w, 16);
-        dw.x += __shfl_xor(dw.x, 32); dw.y += __shfl_xor(dw.y, 32); dw.z += __shfl_xor(dw.z, 32); dw.w += __shfl_xor(dw.w, 32);
-        if (lane < 16) *(float4*)(&dwred[wv][lane * 4]) = dw;
-        __syncthreads();
-        if (threadIdx.x < EMB)
-            a.dw_partial[(size_t)blockIdx.x * EMB + threadIdx.x] =
-                (dwred[0][threadIdx.x] + dwred[1][threadIdx.x]) + (dwred[2][threadIdx.x] + dwred[3][threadIdx.x]);
     }
 }
 
@@ -607,30 +790,34 @@ __global__ __launch_bounds__(256) void k_mse(const float* __restrict__ score, co
     if (threadIdx.x == 0 && loss) *loss = red[0] * scale;
 }
 
-// gradient of Dense(64->1): dO1[k][j] = ds_k*w2[j]; dw2[j] = sum_k ds_k O1[k][j]; db2 = sum_k ds_k.  One block.
+// gradient of Dense(64->1): dO1pre[k][j] = ds_k*w2[j]*[O1[k][j] > 0]; dw2[j] = sum_k ds_k O1[k][j]; db2 = sum_k ds_k.
+// One block per 256 cuts; per-block partial slab [2*64]: dw2 partial, then db2 partial in element 64.
+#define SB_ROWS 256
 __global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_score, const float* __restrict__ o1,
                                                    const float* __restrict__ w2, float* __restrict__ d_o1,
-                                                   float* __restrict__ g_w2, float* __restrict__ g_b2, int n) {
+                                                   float* __restrict__ partial, int n) {
     __shared__ float red[4][EMB];
     __shared__ float red2[256];
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     const float wj = w2[col];
+    const int k0 = blockIdx.x * SB_ROWS, k1 = min(n, k0 + SB_ROWS);
     float gw = 0.f;
-    for (int k = part; k < n; k += 4) {
+    for (int k = k0 + part; k < k1; k += 4) {
         const float ds = d_score[k];
-        gw = fmaf(ds, o1[(size_t)k * EMB + col], gw);
-        d_o1[(size_t)k * EMB + col] = ds * wj;
+        const float ov = o1[(size_t)k * EMB + col];
+        gw = fmaf(ds, ov, gw);
+        d_o1[(size_t)k * EMB + col] = ov > 0.f ? ds * wj : 0.f;  // gradient w.r.t. the pre-activation of out_1 (ReLU mask)
     }
-    float gb = 0.f;
-    for (int k = threadIdx.x; k < n; k += 256) gb += d_score[k];
-    red[part][col] = gw; red2[threadIdx.x] = gb;
+    const int kk = k0 + threadIdx.x;
+    red[part][col] = gw; red2[threadIdx.x] = kk < k1 ? d_score[kk] : 0.f;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red2[threadIdx.x] += red2[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x < EMB) g_w2[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (threadIdx.x == 0) *g_b2 = red2[0];
+    float* slab = partial + (size_t)blockIdx.x * 2 * EMB;
+    if (threadIdx.x < EMB) slab[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) slab[EMB] = red2[0];
 }
 
 // Keras-form Adam (model_trainer.py:131,273): eps outside the bias-corrected sqrt.
@@ -713,7 +900,6 @@ static int launch_edge(bool recv_left, const EdgeArgs& a, int n_edges, hipStream
     const int slots = avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
     const int rpw = 4 / slots;
     int grid = std::min(cdiv(cdiv(a.n_recv, rpw), 4), MAX_GRID);
-    if (MODE == 1) grid = std::min(grid, 1024);  // bounds the number of d w_edge partials
 #define EDGE_CASE(S, RL) hipLaunchKernelGGL((k_edge<S, RL, MODE>), dim3(grid), dim3(256), 0, st, a)
     if (slots == 4) { if (recv_left) EDGE_CASE(4, true); else EDGE_CASE(4, false); }
     else if (slots == 2) { if (recv_left) EDGE_CASE(2, true); else EDGE_CASE(2, false); }
@@ -723,13 +909,6 @@ static int launch_edge(bool recv_left, const EdgeArgs& a, int n_edges, hipStream
     if (grid_out) *grid_out = grid;
     return 0;
 }
-static int edge_bwd_recv_grid(int n_recv, int n_edges) {
-    if (n_recv <= 0) return 0;
-    const double avg = (double)n_edges / (double)n_recv;
-    const int slots = avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
-    return std::min(std::min(cdiv(cdiv(n_recv, 4 / slots), 4), MAX_GRID), 1024);
-}
-
 // ---- workspace carving ------------------------------------------------------------------------------------------
 struct Acts {
     float *E1c, *Xc, *PL1, *S1, *A1, *Z1c, *Xc2, *PL2;          // C rows
@@ -739,14 +918,14 @@ struct Acts {
 struct Work {
     Acts a, g;            // activations and their gradients
     float* partial;       // weight-gradient slabs
-    float* dw_partial[3]; // d w_edge partials per conv
+    float* q[3];          // per-receiver partials of d w_edge, one [R,64] matrix per convolution
     float* emb_partial[3];
-    int dw_nblk[3];
+    float* score_partial; int score_nblk;
     int emb_nblk[3];
     size_t total;
 };
 static inline size_t al4(size_t x) { return (x + 3) & ~(size_t)3; }
-#define EMB1_ROWS 512
+#define EMB1_ROWS 128
 
 static size_t wg_slabs(const gcnn_dims* d) {  // total number of wgrad slabs over all 22 jobs
     const int C = d->n_cons, V = d->n_vars, K = d->n_cuts;
@@ -769,18 +948,16 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
         for (auto p : pk) *p = take(K * EMB);
     }
     w->partial = take(wg_slabs(d) * WG_SLAB);
-    const int nrecv[3] = {d->n_cons, d->n_vars, d->n_cuts};
-    const int ne[3] = {d->n_cons_edges, d->n_cons_edges, d->n_cut_edges};
-    for (int i = 0; i < 3; ++i) {
-        w->dw_nblk[i] = edge_bwd_recv_grid(nrecv[i], ne[i]);
-        w->dw_partial[i] = take((size_t)w->dw_nblk[i] * EMB);
-    }
+    const size_t nrecv[3] = {C, V, K};
+    for (int i = 0; i < 3; ++i) w->q[i] = take(nrecv[i] * EMB);
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
         w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS);
         w->emb_partial[i] = take((size_t)w->emb_nblk[i] * (femb[i] + 1) * EMB);
     }
+    w->score_nblk = cdiv(d->n_cuts, SB_ROWS);
+    w->score_partial = take((size_t)w->score_nblk * 2 * EMB);
     w->total = off;
 }
 
@@ -913,7 +1090,6 @@ int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* 
     EdgeArgs e = edge_args(seg_ptr, oth, coef, p_recv, p_oth, w_edge, e_shift, e_scale, s1, nullptr, s_out, nullptr, n_recv);
     return launch_edge<0>(recv_is_left != 0, e, n_edges, (hipStream_t)stream);
 }
-int32_t gcnn_conv_edge_bwd_partials(int32_t n_recv, int32_t n_edges) { return edge_bwd_recv_grid(n_recv, n_edges); }
 int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv,
                             int32_t n_edges, int32_t recv_is_left, const float* p_recv, const float* p_oth,
                             const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
@@ -935,6 +1111,60 @@ int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const fl
     return launch_edge<2>(send_is_left != 0, e, n_edges, (hipStream_t)stream);
 }
 
+}  // extern "C"
+
+// ---- fused row chains: host-side builders --------------------------------------------------------------------------
+struct Chain {
+    ChArgs a;
+    Chain(int n) { memset(&a, 0, sizeof(a)); a.n = n; }
+    int weight(const float* w) {  // returns the LDS slot of a 64x64 weight, staging each distinct matrix once
+        for (int i = 0; i < a.nw; ++i)
+            if (a.w[i] == w) return i;
+        a.w[a.nw] = w;
+        return a.nw++;
+    }
+    ChStage& gemm(const float* in_a, int ta, const float* w, int transb, float* out, int tout) {
+        ChStage& s = a.st[a.nstage++];
+        s.type = CH_GEMM; s.in_a = in_a; s.ta = ta; s.wa = weight(w); s.transb = transb; s.out = out; s.tout = tout;
+        return s;
+    }
+    ChStage& embed1(const float* x, int f, const float* p, int pb, float* out) {
+        ChStage& s = a.st[a.nstage++];
+        s.type = CH_EMBED1; s.x_raw = x; s.nfeat = f; s.shift = p + poff(pb + E_SHIFT); s.scale = p + poff(pb + E_SCALE);
+        s.w1 = p + poff(pb + E_W1); s.bias = p + poff(pb + E_B1); s.relu = 1; s.out = out; s.tout = 0;
+        return s;
+    }
+    ChStage& score(int ta, const float* w, const float* b, float* out) {
+        ChStage& s = a.st[a.nstage++];
+        s.type = CH_SCORE; s.ta = ta; s.w1 = w; s.bias = b; s.out = out;
+        return s;
+    }
+};
+
+static int launch_chain(const Chain& c, hipStream_t st) {
+    const ChArgs& a = c.a;
+    if (a.n <= 0 || a.nstage == 0) return 0;
+    if (a.nstage > CH_MAX_STAGES || a.nw > CH_MAX_W) return GCNN_E_BADARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_chain<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int ntile = cdiv(a.n, 16);
+    // one block per CU (the staged weights fill most of the LDS); 8 waves per block once there is more than one tile
+    // per wave so two waves share each SIMD's MFMA pipe and hide each other's loads
+    if (ntile > 1024) {
+        const int smem = (a.nw * 64 * LDW + 8 * 2 * CH_TILE) * (int)sizeof(float);
+        hipLaunchKernelGGL(k_chain<8>, dim3(std::min(cdiv(ntile, 8), 256)), dim3(512), smem, st, a);
+    } else {
+        const int smem = (a.nw * 64 * LDW + 4 * 2 * CH_TILE) * (int)sizeof(float);
+        hipLaunchKernelGGL(k_chain<4>, dim3(std::min(cdiv(ntile, 4), 256)), dim3(256), smem, st, a);
+    }
+    LAUNCHCHK();
+    return 0;
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------
 struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-203, 294-296)
     int pbase;            // first parameter index of the block
@@ -942,58 +1172,49 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     bool recv_left;
     const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
     float *PL, *PR, *S, *A, *Z1, *OUT;
-    float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV;
+    float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
 };
 
-static int embed1_fwd(int f, const float* x, const float* p, int pb, float* y, int n, hipStream_t st) {
-    if (n <= 0) return 0;
-    const int grid = std::min(cdiv(n, 16), MAX_GRID);
-    const float *sh = p + poff(pb + E_SHIFT), *sc = p + poff(pb + E_SCALE), *w = p + poff(pb + E_W1), *b = p + poff(pb + E_B1);
-    if (f == 4) hipLaunchKernelGGL(k_embed1_fwd<4>, dim3(grid), dim3(256), 0, st, x, sh, sc, w, b, y, n);
-    else if (f == 14) hipLaunchKernelGGL(k_embed1_fwd<14>, dim3(grid), dim3(256), 0, st, x, sh, sc, w, b, y, n);
-    else hipLaunchKernelGGL(k_embed1_fwd<6>, dim3(grid), dim3(256), 0, st, x, sh, sc, w, b, y, n);
-    LAUNCHCHK();
-    return 0;
+static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = by_left ? c.g->l_ptr : c.g->v_ptr; e.oth = by_left ? c.g->l_oth : c.g->v_oth;
+    e.coef = by_left ? c.g->l_coef : c.g->v_coef;
+    e.p_recv = by_left ? c.PL : c.PR; e.p_oth = by_left ? c.PR : c.PL;   // segment owner's table / gathered table
+    e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
+    e.s1 = p + poff(c.pbase + C_S1); e.n_recv = by_left ? c.nl : c.nv;
+    return e;
 }
 
-static int conv_forward(const float* p, const ConvIO& c, hipStream_t st) {
+// edge pass + the receiver-side update chain S -> A -> Z1 -> X' (model.py:498-508, 568-573); `tail` appends the stages
+// that consume X' (the next convolution's projection or the readout) to the same launch
+template <class Tail>
+static int conv_forward(const float* p, const ConvIO& c, hipStream_t st, Tail tail) {
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
-    // K3/K4: projections (model.py:486-496)
-    LinArgs a = lin_fwd(c.xl, p + poff(c.pbase + C_WL), p + poff(c.pbase + C_BL), 0, c.PL, c.nl);
-    if ((rc = launch_linear(false, a, st))) return rc;
-    a = lin_fwd(c.xv, p + poff(c.pbase + C_WR), nullptr, 0, c.PR, c.nv);
-    if ((rc = launch_linear(false, a, st))) return rc;
-    // K5-K7+K9: fused edge pass
-    EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
-    e.oth = c.recv_left ? c.g->l_oth : c.g->v_oth;
-    e.coef = c.recv_left ? c.g->l_coef : c.g->v_coef;
-    e.p_recv = c.recv_left ? c.PL : c.PR; e.p_oth = c.recv_left ? c.PR : c.PL;
-    e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
-    e.s1 = p + poff(c.pbase + C_S1); e.out = c.S; e.n_recv = nr;
+    EdgeArgs e = conv_edge_args(p, c, c.recv_left);
+    e.out = c.S;
     if ((rc = launch_edge<0>(c.recv_left, e, c.ne, st))) return rc;
-    // K8 hoisted: A = S W_f + deg * b_f
-    a = lin_fwd(c.S, p + poff(c.pbase + C_WF), nullptr, 0, c.A, nr);
-    a.bd = p + poff(c.pbase + C_BF); a.seg_ptr = e.seg_ptr;
-    if ((rc = launch_linear(false, a, st))) return rc;
-    // K10+K11: relu([s2*A | x_recv] W1 + b1), relu(. W2 + b2)
-    a = lin_fwd(c.A, p + poff(c.pbase + C_W1), p + poff(c.pbase + C_B1), 1, c.Z1, nr);
-    a.sa = p + poff(c.pbase + C_S2); a.xb = xrecv; a.wb = p + poff(c.pbase + C_W1) + EMB * EMB;
-    if ((rc = launch_linear(false, a, st))) return rc;
-    a = lin_fwd(c.Z1, p + poff(c.pbase + C_W2), p + poff(c.pbase + C_B2), 1, c.OUT, nr);
-    return launch_linear(false, a, st);
+    Chain ch(nr);
+    ChStage& s0 = ch.gemm(c.S, 0, p + poff(c.pbase + C_WF), 0, c.A, 0);           // A = S Wf + deg*bf (K8 hoisted)
+    s0.bd = p + poff(c.pbase + C_BF); s0.seg_ptr = e.seg_ptr;
+    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 0, c.Z1, 0);      // Z1 = relu([s2*A | x_recv] W1 + b1)
+    s1.sa = p + poff(c.pbase + C_S2); s1.in_b = xrecv; s1.tb = 1; s1.wb = ch.weight(p + poff(c.pbase + C_W1) + EMB * EMB);
+    s1.bias = p + poff(c.pbase + C_B1); s1.relu = 1;
+    ChStage& s2 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 0, c.OUT, 0);     // X' = relu(Z1 W2 + b2)
+    s2.bias = p + poff(c.pbase + C_B2); s2.relu = 1;
+    tail(ch);
+    return launch_chain(ch, st);
 }
 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0]};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1]};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2]};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -1005,38 +1226,51 @@ static int check_common(const gcnn_dims* d, const float* params, const gcnn_grap
     return 0;
 }
 
-int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                  size_t workspace_floats, float* scores, void* stream) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
+    if (d->n_cuts > 0 && !scores) return GCNN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
-    // embeddings (model.py:287-291)
-    if ((rc = embed1_fwd(4, cons_feats, p, P_CONS, A.E1c, d->n_cons, st))) return rc;
-    if ((rc = embed1_fwd(14, var_feats, p, P_VAR, A.E1v, d->n_vars, st))) return rc;
-    if ((rc = embed1_fwd(6, cut_feats, p, P_CUT, A.E1k, d->n_cuts, st))) return rc;
-    LinArgs a = lin_fwd(A.E1c, p + poff(P_CONS + E_W2), p + poff(P_CONS + E_B2), 1, A.Xc, d->n_cons);
-    if ((rc = launch_linear(false, a, st))) return rc;
-    a = lin_fwd(A.E1v, p + poff(P_VAR + E_W2), p + poff(P_VAR + E_B2), 1, A.Xv, d->n_vars);
-    if ((rc = launch_linear(false, a, st))) return rc;
-    a = lin_fwd(A.E1k, p + poff(P_CUT + E_W2), p + poff(P_CUT + E_B2), 1, A.Xk, d->n_cuts);
-    if ((rc = launch_linear(false, a, st))) return rc;
-    // convolutions (model.py:294-296)
-    ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
-    for (int i = 0; i < 3; ++i)
-        if ((rc = conv_forward(p, cv[i], st))) return rc;
-    // readout (model.py:299-300)
-    a = lin_fwd(A.Xk2, p + poff(P_OUT), p + poff(P_OUT + 1), 1, A.O1, d->n_cuts);
-    if ((rc = launch_linear(false, a, st))) return rc;
-    if (d->n_cuts > 0) {
-        if (!scores) return GCNN_E_BADARG;
-        hipLaunchKernelGGL(k_score, dim3(std::min(cdiv(d->n_cuts, 16), MAX_GRID)), dim3(256), 0, st, A.O1,
-                           p + poff(P_OUT + 2), p + poff(P_OUT + 3), scores, d->n_cuts);
-        LAUNCHCHK();
+    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496)
+    {
+        Chain ch(d->n_cons);  // constraints: E1 -> Xc -> PL1
+        ch.embed1(cons_feats, 4, p, P_CONS, A.E1c);
+        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); s.bias = p + poff(P_CONS + E_B2); s.relu = 1;
+        ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); t.bias = p + poff(P_CONV0 + C_BL);
+        if ((rc = launch_chain(ch, st))) return rc;
     }
+    {
+        Chain ch(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
+        ch.embed1(var_feats, 14, p, P_VAR, A.E1v);
+        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 0, A.Xv, 0); s.bias = p + poff(P_VAR + E_B2); s.relu = 1;
+        ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WR), 0, A.PR1, 1);
+        ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WR), 0, A.PR2, 1);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    {
+        Chain ch(d->n_cuts);  // cuts: E1 -> Xk -> PL3
+        ch.embed1(cut_feats, 6, p, P_CUT, A.E1k);
+        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); s.bias = p + poff(P_CUT + E_B2); s.relu = 1;
+        ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); t.bias = p + poff(P_CONV2 + C_BL);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
+    ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+    if ((rc = conv_forward(p, cv[0], st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
+            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WL), 0, A.PL2, 1); t.bias = p + poff(P_CONV1 + C_BL);
+        }))) return rc;
+    if ((rc = conv_forward(p, cv[1], st, [&](Chain& ch) {   // updated variables -> right projection of conv v->k
+            ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WR), 0, A.PR3, 1);
+        }))) return rc;
+    if ((rc = conv_forward(p, cv[2], st, [&](Chain& ch) {   // updated cuts -> readout (model.py:206-208, 299-300)
+            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_OUT), 0, A.O1, 0); t.bias = p + poff(P_OUT + 1); t.relu = 1;
+            ch.score(0, p + poff(P_OUT + 2), p + poff(P_OUT + 3), scores);
+        }))) return rc;
     return 0;
 }
 
@@ -1045,14 +1279,12 @@ struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
 };
-static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr, int n,
-                   float* gw, float* gb, float* gbd, float* partial) {
-    if (n <= 0) {  // empty input: gradients are exactly zero
-        return;
-    }
+static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr, const float* d2,
+                   int n, float* gw, float* gb, float* g2, float* partial) {
+    if (n <= 0) return;  // empty input: gradients are exactly zero
     WgJob& j = jl.wg.job[jl.wg.njobs++];
     const int nb = cdiv(n, WG_ROWS);
-    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
+    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.d2 = d2; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
     const float* src = partial + (size_t)jl.nslab * WG_SLAB;
     jl.wg.nblocks += nb; jl.nslab += nb;
     auto rd = [&](const float* s, float* dst, int len) {
@@ -1062,7 +1294,7 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
     };
     rd(src, gw, EMB * EMB);
     if (gb) rd(src + EMB * EMB, gb, EMB);
-    if (gbd) rd(src + EMB * EMB + EMB, gbd, EMB);
+    if (g2) rd(src + EMB * EMB + EMB, g2, EMB);
 }
 static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int stride, int len) {
     if (nparts <= 0) return;
@@ -1071,58 +1303,38 @@ static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int st
     jl.rdblk += cdiv(len, EMB);
 }
 
-static int conv_backward(const float* p, float* grads, const ConvIO& c, const Work& w, int ci, int beta_xl, int beta_xv,
-                         JobList& jl, hipStream_t st) {
+// Receiver-side gradient chain of one convolution, appended to `ch` whose tile 0 already holds dX' (masked):
+//   dZ1 = dX'pre W2^T (mask Z1) ; d x_recv = dZ1pre W1b^T ; dA = s2 * dZ1pre W1a^T ; dS = dA Wf^T
+static void conv_bwd_chain(Chain& ch, const float* p, const ConvIO& c) {
+    float* gxrecv = c.recv_left ? c.gXL : c.gXV;
+    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 1, c.gZ1, 0); s1.mask = c.Z1;
+    ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1) + EMB * EMB, 1, gxrecv, 1);
+    ChStage& s3 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 1, c.gA, 0); s3.so = p + poff(c.pbase + C_S2);
+    ch.gemm(nullptr, 0, p + poff(c.pbase + C_WF), 1, c.gS, 0);
+}
+
+// gradients of the edge pass: sender-ordered pass then receiver-ordered pass (which also emits Q, the per-receiver
+// partial of d w_edge), and the weight-gradient jobs of the whole convolution
+static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, const Work& w, JobList& jl, hipStream_t st) {
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
-    float* gxrecv = c.recv_left ? c.gXL : c.gXV;
-    int& beta_recv = c.recv_left ? beta_xl : beta_xv;
-    const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
-    // out = relu(Z1 W2 + b2): dZ1 = (dOut * mask) W2^T
-    LinArgs a = lin_bwd(c.gOUT, c.OUT, p + poff(c.pbase + C_W2), c.gZ1, 0, nr);
-    if ((rc = launch_linear(true, a, st))) return rc;
-    // Z1 = relu(s2*A W1a + xrecv W1b + b1): dA = s2 * dZ1pre W1a^T ; dxrecv (+)= dZ1pre W1b^T
-    a = lin_bwd(c.gZ1, c.Z1, p + poff(c.pbase + C_W1), c.gA, 0, nr);
-    a.so = p + poff(c.pbase + C_S2); a.wb = p + poff(c.pbase + C_W1) + EMB * EMB; a.y2 = gxrecv; a.beta_y2 = beta_recv;
-    beta_recv = 1;
-    if ((rc = launch_linear(true, a, st))) return rc;
-    // A = S Wf + deg bf: dS = dA Wf^T
-    a = lin_bwd(c.gA, nullptr, p + poff(c.pbase + C_WF), c.gS, 0, nr);
-    if ((rc = launch_linear(true, a, st))) return rc;
-    // edge pass gradients
-    EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
-    e.s1 = p + poff(c.pbase + C_S1);
-    // (1) receiver-ordered: dP_recv[r] and d w_edge
-    e.seg_ptr = seg; e.oth = c.recv_left ? c.g->l_oth : c.g->v_oth; e.coef = c.recv_left ? c.g->l_coef : c.g->v_coef;
-    e.p_recv = c.recv_left ? c.PL : c.PR; e.p_oth = c.recv_left ? c.PR : c.PL;
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPL : c.gPR; e.dw_partial = w.dw_partial[ci]; e.n_recv = nr;
-    int g = 0;
-    if (edge_bwd_recv_grid(nr, c.ne) > w.dw_nblk[ci]) return GCNN_E_WORKSPACE;
-    if ((rc = launch_edge<1>(c.recv_left, e, c.ne, st, &g))) return rc;
-    add_rd(jl, w.dw_partial[ci], grads + poff(c.pbase + C_WE), g, EMB, EMB);
-    // (2) sender-ordered: dP_send[u] = sum over the sender's edges, gathering P_recv and dS rows
-    const int ns = c.recv_left ? c.nv : c.nl;
-    e.seg_ptr = c.recv_left ? c.g->v_ptr : c.g->l_ptr; e.oth = c.recv_left ? c.g->v_oth : c.g->l_oth;
-    e.coef = c.recv_left ? c.g->v_coef : c.g->l_coef;
-    e.p_recv = c.recv_left ? c.PR : c.PL;  /* segment owner = sender */
-    e.p_oth = c.recv_left ? c.PL : c.PR;   /* gathered = receiver rows */
-    e.out = c.recv_left ? c.gPR : c.gPL; e.dw_partial = nullptr; e.n_recv = ns;
-    // segment owner is the left node iff the receiver is the variable side
+    EdgeArgs e = conv_edge_args(p, c, c.recv_left);
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPL : c.gPR; e.dw_partial = c.Q;
+    if ((rc = launch_edge<1>(c.recv_left, e, c.ne, st))) return rc;
+    e = conv_edge_args(p, c, !c.recv_left);   // segments owned by the sender; receiver rows and dS are gathered
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL;
     if ((rc = launch_edge<2>(!c.recv_left, e, c.ne, st))) return rc;
-    // projections: dXL (+)= dPL Wl^T ; dXV (+)= dPR Wr^T
-    a = lin_bwd(c.gPL, nullptr, p + poff(c.pbase + C_WL), c.gXL, beta_xl, c.nl);
-    if ((rc = launch_linear(true, a, st))) return rc;
-    a = lin_bwd(c.gPR, nullptr, p + poff(c.pbase + C_WR), c.gXV, beta_xv, c.nv);
-    if ((rc = launch_linear(true, a, st))) return rc;
-    // weight-gradient jobs (all read buffers that stay untouched until the grouped launch)
-    add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
-    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
-    add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
-    add_wg(jl, c.S, nullptr, c.gA, seg, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
-    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.nl, grads + poff(c.pbase + C_WL), grads + poff(c.pbase + C_BL), nullptr, w.partial);
-    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr, nullptr, w.partial);
+    const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
+    float* gwe = grads + poff(c.pbase + C_WE);
+    add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
+    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
+    add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
+    add_wg(jl, c.S, nullptr, c.gA, seg, nullptr, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
+    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.recv_left ? c.Q : nullptr, c.nl, grads + poff(c.pbase + C_WL),
+           grads + poff(c.pbase + C_BL), c.recv_left ? gwe : nullptr, w.partial);
+    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.recv_left ? nullptr : c.Q, c.nv, grads + poff(c.pbase + C_WR), nullptr,
+           c.recv_left ? nullptr : gwe, w.partial);
     return 0;
 }
 
@@ -1137,7 +1349,7 @@ static int embed1_wgrad(int f, const float* x, const float* p, int pb, const flo
     return 0;
 }
 
-int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out, float* d_scores,
+extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out, float* d_scores,
                   void* stream) {
     if (n < 0 || (n > 0 && (!scores || !targets))) return GCNN_E_BADARG;
     if (n == 0) {
@@ -1149,7 +1361,7 @@ int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float sc
     return 0;
 }
 
-int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                   size_t workspace_floats, const float* d_scores, float* grads, void* stream) {
     layout_init();
@@ -1164,33 +1376,62 @@ int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, c
     // every trainable gradient is (re)written below only if its inputs are non-empty: start from zero
     HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
     if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
-
-    // Dense(64->1) gradient (model.py:208)
-    hipLaunchKernelGGL(k_score_bwd, dim3(1), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
-                       grads + poff(P_OUT + 2), grads + poff(P_OUT + 3), d->n_cuts);
-    LAUNCHCHK();
-    LinArgs a = lin_bwd(G.O1, A.O1, p + poff(P_OUT), G.Xk2, 0, d->n_cuts);
-    if ((rc = launch_linear(true, a, st))) return rc;
-    add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
-
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
-    // first-writer bookkeeping of the accumulated node gradients: 0 = overwrite, 1 = accumulate
-    // conv3 (cut): recv=left(Xk): gXk first written by W1b; gXv2 written by Wr (first).
-    if ((rc = conv_backward(p, grads, cv[2], w, 2, /*beta_xl (gXk)*/ 0, /*beta_xv (gXv2)*/ 0, jl, st))) return rc;
-    // conv2 (var): recv=var(Xv): gXv first written by W1b; gXc2 written by Wl (first).
-    if ((rc = conv_backward(p, grads, cv[1], w, 1, /*beta_xl (gXc2)*/ 0, /*beta_xv (gXv)*/ 0, jl, st))) return rc;
-    // conv1 (cons): recv=left(Xc): gXc first written by W1b; gXv accumulates.
-    if ((rc = conv_backward(p, grads, cv[0], w, 0, /*beta_xl (gXc)*/ 0, /*beta_xv (gXv)*/ 1, jl, st))) return rc;
 
-    // embeddings, second layer: X = relu(E1 W2 + b2)
-    struct { const float* x; const float* e1; const float* xo; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
-        {cons_feats, A.E1c, A.Xc, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
-        {var_feats, A.E1v, A.Xv, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
-        {cut_feats, A.E1k, A.Xk, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
+    // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
+    hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
+                       w.score_partial, d->n_cuts);
+    LAUNCHCHK();
+    add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), w.score_nblk, 2 * EMB, EMB);
+    add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), w.score_nblk, 2 * EMB, 1);
+    add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
+    {   // cut rows: readout -> conv v->k receiver chain
+        Chain ch(d->n_cuts);
+        ChStage& s0 = ch.gemm(G.O1, 0, p + poff(P_OUT), 1, G.Xk2, 0); s0.mask = A.Xk2;
+        conv_bwd_chain(ch, p, cv[2]);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    if ((rc = conv_backward_edges(p, grads, cv[2], w, jl, st))) return rc;
+    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
+        Chain ch(d->n_cuts);
+        ChStage& s0 = ch.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); s0.add = G.Xk; s0.mask = A.Xk;
+        ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain
+        Chain ch(d->n_vars);
+        ChStage& s0 = ch.gemm(G.PR3, 0, p + poff(P_CONV2 + C_WR), 1, G.Xv2, 0); s0.mask = A.Xv2;
+        conv_bwd_chain(ch, p, cv[1]);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
+    {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver chain
+        Chain ch(d->n_cons);
+        ChStage& s0 = ch.gemm(G.PL2, 0, p + poff(P_CONV1 + C_WL), 1, G.Xc2, 0); s0.mask = A.Xc2;
+        conv_bwd_chain(ch, p, cv[0]);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    if ((rc = conv_backward_edges(p, grads, cv[0], w, jl, st))) return rc;
+    {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v
+        Chain ch(d->n_vars);
+        ChStage& s0 = ch.gemm(G.PR2, 0, p + poff(P_CONV1 + C_WR), 1, G.Xv, 0);
+        s0.in_b = G.PR1; s0.tb = 1; s0.wb = ch.weight(p + poff(P_CONV0 + C_WR)); s0.add = G.Xv; s0.mask = A.Xv;
+        ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
+        Chain ch(d->n_cons);
+        ChStage& s0 = ch.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); s0.add = G.Xc; s0.mask = A.Xc;
+        ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    // embeddings: second-layer weight jobs, first-layer weight gradients on the VALU
+    struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
+        {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
+        {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
+        {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
     for (int i = 0; i < 3; ++i) {
-        a = lin_bwd(em[i].gx, em[i].xo, p + poff(em[i].pb + E_W2), em[i].ge1, 0, em[i].n);
-        if ((rc = launch_linear(true, a, st))) return rc;
-        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
+        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
         if ((rc = embed1_wgrad(em[i].f, em[i].x, p, em[i].pb, em[i].ge1, em[i].e1, w.emb_partial[i], em[i].n, w.emb_nblk[i], st))) return rc;
         // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
         add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
@@ -1208,7 +1449,7 @@ int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, c
     return 0;
 }
 
-int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1, float beta2,
+extern "C" int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1, float beta2,
                    float eps, const float* grad_scale, void* stream) {
     if (n < 0 || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
     if (n == 0) return 0;
@@ -1217,5 +1458,3 @@ int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_
     LAUNCHCHK();
     return 0;
 }
-
-}  // extern "C"

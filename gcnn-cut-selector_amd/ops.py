@@ -73,8 +73,7 @@ def conv_edge_bwd(graph: BipartiteGraph, recv_is_left: bool, pl, pr, w_edge, e_s
     ptr, oth, coef, n_recv = _edge_side(graph, recv_is_left)
     p_recv, p_oth = (pl, pr) if recv_is_left else (pr, pl)
     d_recv = torch.empty((n_recv, EMB), dtype=torch.float32, device=dev)
-    nparts = lib.gcnn_conv_edge_bwd_partials(n_recv, graph.n_edges)
-    parts = torch.zeros((max(nparts, 1), EMB), dtype=torch.float32, device=dev)
+    parts = torch.zeros((max(n_recv, 1), EMB), dtype=torch.float32, device=dev)  # per-receiver shares of d w_edge
     with torch.cuda.device(dev):
         _lib.check(lib.gcnn_conv_edge_bwd_recv(_ptr(ptr), _ptr(oth), _ptr(coef), n_recv, graph.n_edges, int(recv_is_left),
                                                _ptr(p_recv), _ptr(p_oth), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale),

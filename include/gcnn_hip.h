@@ -84,17 +84,16 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * ((PL[l_e] + c_e*w_edge) + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
  *           p_recv = projected table of the receiving side [n_recv,64], p_oth = the other side's table, gathered by
  *           oth[e]; recv_is_left: receiver is the constraint/cut side (from_v=True, model.py:553-556).
- * bwd_recv: d_p_recv[r] = sum_e dJ_e, dJ_e = s1*d_s[r]*[s1*J_e > 0]; dw_partial: [gcnn_conv_edge_bwd_partials(..)][64]
- *           per-block partial sums of d w_edge = sum_e c_e dJ_e (reduce in order for the final gradient).
+ * bwd_recv: d_p_recv[r] = sum_e dJ_e, dJ_e = s1*d_s[r]*[s1*J_e > 0]; dw_rows: [n_recv,64], row r = sum_{e in seg(r)} c_e dJ_e,
+ *           this receiver's share of d w_edge (its column sum is the gradient of feature_module_edge, model.py:490-492).
  * bwd_send: segments grouped by the SENDING node: d_p_send[u] = sum_{e in seg(u)} s1*d_s[oth_e]*[s1*J_e > 0]. */
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
                        const float* e_shift, const float* e_scale, const float* s1, float* s_out, void* stream);
-int32_t gcnn_conv_edge_bwd_partials(int32_t n_recv, int32_t n_edges);
 int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv,
                             int32_t n_edges, int32_t recv_is_left, const float* p_recv, const float* p_oth,
                             const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
-                            const float* d_s, float* d_p_recv, float* dw_partial, void* stream);
+                            const float* d_s, float* d_p_recv, float* dw_rows, void* stream);
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send,
                             int32_t n_edges, int32_t send_is_left, const float* p_send, const float* p_recv,
                             const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
