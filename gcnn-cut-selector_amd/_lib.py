@@ -25,7 +25,8 @@ class Dims(C.Structure):
 
 class Graph(C.Structure):
     _fields_ = [("l_ptr", C.c_void_p), ("l_oth", C.c_void_p), ("l_coef", C.c_void_p),
-                ("v_ptr", C.c_void_p), ("v_oth", C.c_void_p), ("v_coef", C.c_void_p)]
+                ("v_ptr", C.c_void_p), ("v_oth", C.c_void_p), ("v_coef", C.c_void_p),
+                ("l2v", C.c_void_p), ("v2l", C.c_void_p)]
 
 
 _P, _I, _F, _Z = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
@@ -38,14 +39,14 @@ SIGNATURES = {
     "gcnn_param_total_floats": (C.c_int, []),
     "gcnn_param_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
     "gcnn_graph_temp_bytes": (_Z, [_I]),
-    "gcnn_graph_build": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "gcnn_graph_build": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "gcnn_seg_sum_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
     "gcnn_seg_bcast_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
     "gcnn_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "gcnn_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
-    "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "gcnn_workspace_floats": (_Z, [_DP]),
     "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P]),
     "gcnn_mse_loss": (C.c_int, [_P, _P, _I, _F, _P, _P, _P]),

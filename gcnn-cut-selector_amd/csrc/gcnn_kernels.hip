@@ -607,11 +607,13 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 struct EdgeArgs {
     const int* seg_ptr; const int* oth; const float* coef;
-    const float* p_recv; const float* p_oth;      // projected tables [R,64], [Nother,64]
+    const float* p_recv; const float* p_oth;      // forward: projected tables of the segment owner [R,64] / the gathered side
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
-    const float* d_s;                              // backward only: dS [R,64] (recv pass) or gathered (send pass)
+    const float* d_s;                              // backward: dS [R,64] (own row in the recv pass, gathered in the send pass)
+    const int* xpos;                               // send pass: position of each edge in the receiver-ordered list
+    unsigned long long* mask;                      // [E] ReLU masks in receiver order: written by forward, read by backward
     float* out;                                    // S (fwd) / dP_recv / dP_send
-    float* dw_partial;                             // backward recv pass: Q [R,64], per-receiver partial of d w_edge
+    float* dw_rows;                                // recv pass: Q [R,64], per-receiver share of d w_edge
     int n_recv;
 };
 
@@ -626,13 +628,18 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
     return v;
 }
 
-// MODE 0: forward; MODE 1: backward, receiver-ordered (dP_recv + d w_edge); MODE 2: backward, sender-ordered (dP_send:
-// here "recv" in the argument names means the node that owns the segment, i.e. the sender, and d_s is gathered).
-template <int SLOTS, bool OWNER_LEFT, int MODE>
-__global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
+// The 64 ReLU bits of one edge: bit (16*k + c) belongs to channel 4*c + k (lane c of the 16-lane group, component k).
+__device__ __forceinline__ float4 mask_bits(unsigned lo, unsigned hi, int c) {
+    return make_float4((float)((lo >> c) & 1u), (float)((lo >> (16 + c)) & 1u), (float)((hi >> c) & 1u),
+                       (float)((hi >> (16 + c)) & 1u));
+}
+
+// Forward.  OWNER_LEFT: the receiver is the left node (constraint/cut; from_v=True, model.py:553-556).
+template <int SLOTS, bool OWNER_LEFT>
+__global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, ch = (gl & 15) * 4;
+    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, ch = (gl & 15) * 4, q16 = (lane >> 4) * 16;
     const float4 w = *(const float4*)(a.w_edge + ch);
     const float esh = *a.e_shift, esc = *a.e_scale, s1 = *a.s1;
 
@@ -642,16 +649,14 @@ __global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
         if (r < a.n_recv) {
             const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
             const float4 pown = *(const float4*)(a.p_recv + (size_t)r * EMB + ch);
-            float4 down = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE == 1) down = *(const float4*)(a.d_s + (size_t)r * EMB + ch);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int base = beg; base < end; base += G) {
                 const int e = base + gl;
                 int o = 0; float c = 0.f;
                 if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
                 const int cnt = min(G, end - base);
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4], dg[4];
+                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int i = i0 + u * SLOTS + slot;
@@ -661,45 +666,130 @@ __global__ __launch_bounds__(256) void k_edge(EdgeArgs a) {
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        p[u] = make_float4(0.f, 0.f, 0.f, 0.f); dg[u] = p[u];
-                        if (ok[u]) {
-                            p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
-                            if (MODE == 2) dg[u] = *(const float4*)(a.d_s + (size_t)oi[u] * EMB + ch);
-                        }
+                        p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (!ok[u]) continue;
                         const float cw[4] = {__fmul_rn(ci[u], w.x), __fmul_rn(ci[u], w.y), __fmul_rn(ci[u], w.z),
                                              __fmul_rn(ci[u], w.w)};
                         const float pw[4] = {pown.x, pown.y, pown.z, pown.w};
                         const float po[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
                         float hj[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
+                        for (int k = 0; k < 4; ++k) {
                             hj[k] = s1 * (OWNER_LEFT ? jointf(pw[k], cw[k], po[k]) : jointf(po[k], cw[k], pw[k]));
-                        if (MODE == 0) {
-                            acc.x += fmaxf(hj[0], 0.f); acc.y += fmaxf(hj[1], 0.f);
-                            acc.z += fmaxf(hj[2], 0.f); acc.w += fmaxf(hj[3], 0.f);
-                        } else {
-                            const float4 dsv = MODE == 1 ? down : dg[u];
-                            const float dj[4] = {hj[0] > 0.f ? s1 * dsv.x : 0.f, hj[1] > 0.f ? s1 * dsv.y : 0.f,
-                                                 hj[2] > 0.f ? s1 * dsv.z : 0.f, hj[3] > 0.f ? s1 * dsv.w : 0.f};
-                            acc.x += dj[0]; acc.y += dj[1]; acc.z += dj[2]; acc.w += dj[3];
-                            if (MODE == 1) {
-                                dw.x = fmaf(ci[u], dj[0], dw.x); dw.y = fmaf(ci[u], dj[1], dw.y);
-                                dw.z = fmaf(ci[u], dj[2], dw.z); dw.w = fmaf(ci[u], dj[3], dw.w);
-                            }
+                            hj[k] = ok[u] ? fmaxf(hj[k], 0.f) : 0.f;
+                        }
+                        acc.x += hj[0]; acc.y += hj[1]; acc.z += hj[2]; acc.w += hj[3];
+                        if (a.mask) {  // 4 ballots = the 64 bits of each of the (up to) four edges this wave just did
+                            const unsigned long long b0 = __ballot(hj[0] > 0.f), b1 = __ballot(hj[1] > 0.f);
+                            const unsigned long long b2 = __ballot(hj[2] > 0.f), b3 = __ballot(hj[3] > 0.f);
+                            if (ok[u] && (lane & 15) == 0)
+                                a.mask[base + i0 + u * SLOTS + slot] =
+                                    ((b0 >> q16) & 0xffffull) | (((b1 >> q16) & 0xffffull) << 16) |
+                                    (((b2 >> q16) & 0xffffull) << 32) | (((b3 >> q16) & 0xffffull) << 48);
                         }
                     }
                 }
             }
             acc = slot_reduce<SLOTS>(acc);
             if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = acc;
-            if (MODE == 1) {  // Q[r] = sum_e c_e dJ_e: this receiver's share of d w_edge, column-summed by k_wgrad
-                dw = slot_reduce<SLOTS>(dw);
-                if (slot == 0) *(float4*)(a.dw_partial + (size_t)r * EMB + ch) = dw;
+        }
+    }
+}
+
+// Backward, receiver-ordered: dJ_e = s1 * dS[r] * mask_e, so with dS[r] constant over the segment
+//   dP_recv[r] = s1 * dS[r] * (#set bits per channel),   Q[r] = s1 * dS[r] * sum_e c_e * mask_e   (no row gathers)
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_edge_bwd_recv(EdgeArgs a) {
+    constexpr int G = 16 * SLOTS, RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
+    const float esh = *a.e_shift, esc = *a.e_scale, s1 = *a.s1;
+    const int nwork = (a.n_recv + RPW - 1) / RPW;
+    for (int item = blockIdx.x * 4 + wv; item < nwork; item += gridDim.x * 4) {
+        const int r = item * RPW + lane / G;
+        if (r < a.n_recv) {
+            const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
+            const float4 ds = *(const float4*)(a.d_s + (size_t)r * EMB + ch);
+            float4 cnt4 = make_float4(0.f, 0.f, 0.f, 0.f), cw4 = cnt4;
+            for (int base = beg; base < end; base += G) {
+                const int e = base + gl;
+                unsigned lo = 0, hi = 0; float c = 0.f;
+                if (e < end) {
+                    const unsigned long long m = a.mask[e];
+                    lo = (unsigned)m; hi = (unsigned)(m >> 32); c = (a.coef[e] + esh) * esc;
+                }
+                const int cnt = min(G, end - base);
+                for (int i0 = 0; i0 < cnt; i0 += SLOTS) {  // group-uniform trip count: a shuffle must not read an exited lane
+                    const int i = i0 + slot;
+                    const bool ok = i < cnt;
+                    const int src = gbase + (ok ? i : 0);
+                    float4 b = mask_bits(__shfl(lo, src), __shfl(hi, src), cl);
+                    if (!ok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float ci = __shfl(c, src);
+                    cnt4.x += b.x; cnt4.y += b.y; cnt4.z += b.z; cnt4.w += b.w;
+                    cw4.x = fmaf(ci, b.x, cw4.x); cw4.y = fmaf(ci, b.y, cw4.y); cw4.z = fmaf(ci, b.z, cw4.z); cw4.w = fmaf(ci, b.w, cw4.w);
+                }
             }
+            cnt4 = slot_reduce<SLOTS>(cnt4); cw4 = slot_reduce<SLOTS>(cw4);
+            if (slot == 0) {
+                const float4 sd = make_float4(s1 * ds.x, s1 * ds.y, s1 * ds.z, s1 * ds.w);
+                *(float4*)(a.out + (size_t)r * EMB + ch) = make_float4(sd.x * cnt4.x, sd.y * cnt4.y, sd.z * cnt4.z, sd.w * cnt4.w);
+                *(float4*)(a.dw_rows + (size_t)r * EMB + ch) = make_float4(sd.x * cw4.x, sd.y * cw4.y, sd.z * cw4.z, sd.w * cw4.w);
+            }
+        }
+    }
+}
+
+// Backward, sender-ordered: dP_send[u] = s1 * sum_{e in seg(u)} mask_e * dS[recv(e)]: one 256-B row gather and one 8-B
+// mask gather (through xpos, the edge's position in the receiver-ordered list) per edge.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
+    constexpr int G = 16 * SLOTS, RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
+    const float s1 = *a.s1;
+    const int nwork = (a.n_recv + RPW - 1) / RPW;
+    for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
+        const int u = item * RPW + lane / G;
+        if (u < a.n_recv) {
+            const int beg = a.seg_ptr[u], end = a.seg_ptr[u + 1];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int base = beg; base < end; base += G) {
+                const int e = base + gl;
+                int o = 0; unsigned lo = 0, hi = 0;
+                if (e < end) {
+                    o = a.oth[e];
+                    const unsigned long long m = a.mask[a.xpos[e]];
+                    lo = (unsigned)m; hi = (unsigned)(m >> 32);
+                }
+                const int cnt = min(G, end - base);
+                for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
+                    int oi[4]; bool ok[4]; float4 b[4], d[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = i0 + v * SLOTS + slot;
+                        ok[v] = i < cnt;
+                        const int src = gbase + (ok[v] ? i : 0);
+                        oi[v] = __shfl(o, src);
+                        b[v] = mask_bits(__shfl(lo, src), __shfl(hi, src), cl);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        d[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok[v]) d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        acc.x = fmaf(b[v].x, d[v].x, acc.x); acc.y = fmaf(b[v].y, d[v].y, acc.y);
+                        acc.z = fmaf(b[v].z, d[v].z, acc.z); acc.w = fmaf(b[v].w, d[v].w, acc.w);
+                    }
+                }
+            }
+            acc = slot_reduce<SLOTS>(acc);
+            if (slot == 0) *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
         }
     }
 }
@@ -848,6 +938,14 @@ __global__ void k_seg_offsets(const int* __restrict__ keys, int n, int n_seg, in
         for (int k = lo + 1; k <= hi; ++k) ptr[k] = i;
     }
 }
+// inv[perm[i]] = i
+__global__ void k_invert_perm(const int* __restrict__ perm, int n, int* __restrict__ inv) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) inv[perm[i]] = i;
+}
+// out[i] = inv[perm[i]]
+__global__ void k_compose_perm(const int* __restrict__ perm, const int* __restrict__ inv, int n, int* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = inv[perm[i]];
+}
 __global__ void k_gather_edges(const int* __restrict__ perm, const int* __restrict__ other, const float* __restrict__ coef,
                                int n, int* __restrict__ oth_out, float* __restrict__ coef_out) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -892,23 +990,31 @@ static LinArgs lin_bwd(const float* dy, const float* ymask, const float* wa, flo
     return a;
 }
 
+static inline int edge_slots(int n_own, int n_edges) {
+    const double avg = (double)n_edges / (double)std::max(n_own, 1);
+    return avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
+}
+// MODE 0: forward (owner = receiver), 1: backward receiver-ordered, 2: backward sender-ordered (owner = sender)
 template <int MODE>
-static int launch_edge(bool recv_left, const EdgeArgs& a, int n_edges, hipStream_t st, int* grid_out = nullptr) {
-    if (grid_out) *grid_out = 0;
+static int launch_edge(bool owner_left, const EdgeArgs& a, int n_edges, hipStream_t st) {
     if (a.n_recv <= 0) return 0;
-    const double avg = (double)n_edges / (double)a.n_recv;
-    const int slots = avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
-    const int rpw = 4 / slots;
-    int grid = std::min(cdiv(cdiv(a.n_recv, rpw), 4), MAX_GRID);
-#define EDGE_CASE(S, RL) hipLaunchKernelGGL((k_edge<S, RL, MODE>), dim3(grid), dim3(256), 0, st, a)
-    if (slots == 4) { if (recv_left) EDGE_CASE(4, true); else EDGE_CASE(4, false); }
-    else if (slots == 2) { if (recv_left) EDGE_CASE(2, true); else EDGE_CASE(2, false); }
-    else { if (recv_left) EDGE_CASE(1, true); else EDGE_CASE(1, false); }
-#undef EDGE_CASE
+    const int slots = edge_slots(a.n_recv, n_edges);
+    const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
+#define EDGE_LAUNCH(K) hipLaunchKernelGGL((K), dim3(grid), dim3(256), 0, st, a)
+    if (MODE == 0) {
+        if (slots == 4) { if (owner_left) EDGE_LAUNCH((k_edge_fwd<4, true>)); else EDGE_LAUNCH((k_edge_fwd<4, false>)); }
+        else if (slots == 2) { if (owner_left) EDGE_LAUNCH((k_edge_fwd<2, true>)); else EDGE_LAUNCH((k_edge_fwd<2, false>)); }
+        else { if (owner_left) EDGE_LAUNCH((k_edge_fwd<1, true>)); else EDGE_LAUNCH((k_edge_fwd<1, false>)); }
+    } else if (MODE == 1) {
+        if (slots == 4) EDGE_LAUNCH(k_edge_bwd_recv<4>); else if (slots == 2) EDGE_LAUNCH(k_edge_bwd_recv<2>); else EDGE_LAUNCH(k_edge_bwd_recv<1>);
+    } else {
+        if (slots == 4) EDGE_LAUNCH(k_edge_bwd_send<4>); else if (slots == 2) EDGE_LAUNCH(k_edge_bwd_send<2>); else EDGE_LAUNCH(k_edge_bwd_send<1>);
+    }
+#undef EDGE_LAUNCH
     LAUNCHCHK();
-    if (grid_out) *grid_out = grid;
     return 0;
 }
+
 // ---- workspace carving ------------------------------------------------------------------------------------------
 struct Acts {
     float *E1c, *Xc, *PL1, *S1, *A1, *Z1c, *Xc2, *PL2;          // C rows
@@ -919,6 +1025,7 @@ struct Work {
     Acts a, g;            // activations and their gradients
     float* partial;       // weight-gradient slabs
     float* q[3];          // per-receiver partials of d w_edge, one [R,64] matrix per convolution
+    unsigned long long* mask[3];  // ReLU masks of the three edge passes, 64 bits per edge, receiver order
     float* emb_partial[3];
     float* score_partial; int score_nblk;
     int emb_nblk[3];
@@ -950,6 +1057,8 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     w->partial = take(wg_slabs(d) * WG_SLAB);
     const size_t nrecv[3] = {C, V, K};
     for (int i = 0; i < 3; ++i) w->q[i] = take(nrecv[i] * EMB);
+    const size_t nedge[3] = {(size_t)d->n_cons_edges, (size_t)d->n_cons_edges, (size_t)d->n_cut_edges};
+    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned long long*)take(2 * nedge[i]);
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
@@ -991,12 +1100,12 @@ static size_t sort_temp_bytes(int n) {
 }
 size_t gcnn_graph_temp_bytes(int32_t n_edges) {
     const size_t e = ((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int) + 255) & ~(size_t)255;
-    return sort_temp_bytes(n_edges) + 3 * e;  // cub temp + iota + sorted keys + perm
+    return sort_temp_bytes(n_edges) + 5 * e;  // cub temp + iota + sorted keys + two permutations + one inverse
 }
 
 int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left, int32_t n_var,
                      int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth, float* v_coef,
-                     int32_t* l_perm, void* temp, size_t temp_bytes, void* stream) {
+                     int32_t* l2v, int32_t* v2l, int32_t* l_perm, void* temp, size_t temp_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_edges < 0 || n_left < 0 || n_var < 0 || !l_ptr || !v_ptr) return GCNN_E_BADARG;
     if (temp_bytes < gcnn_graph_temp_bytes(n_edges)) return GCNN_E_WORKSPACE;
@@ -1012,7 +1121,8 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
     void* cub_tmp = t;
     int* iota = (int*)(t + cub_bytes);
     int* keys = (int*)(t + cub_bytes + e);
-    int* perm = (int*)(t + cub_bytes + 2 * e);
+    int* perm[2] = {(int*)(t + cub_bytes + 2 * e), (int*)(t + cub_bytes + 3 * e)};
+    int* inv = (int*)(t + cub_bytes + 4 * e);
     const int grid = std::min(cdiv(n_edges + 1, 256), 4096);
     const int* left = edge_inds;
     const int* var = edge_inds + n_edges;
@@ -1023,14 +1133,22 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
         const int nseg = side == 0 ? n_left : n_var;
         int bits = 1;
         while ((1ll << bits) < (long long)nseg + 1 && bits < 31) ++bits;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, keys, (const int*)iota, perm, n_edges, 0,
-                                                  bits, st));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, keys, (const int*)iota, perm[side], n_edges,
+                                                  0, bits, st));
         hipLaunchKernelGGL(k_seg_offsets, dim3(grid), dim3(256), 0, st, keys, n_edges, nseg, side == 0 ? l_ptr : v_ptr);
         LAUNCHCHK();
-        hipLaunchKernelGGL(k_gather_edges, dim3(grid), dim3(256), 0, st, perm, side == 0 ? var : left, edge_feats,
+        hipLaunchKernelGGL(k_gather_edges, dim3(grid), dim3(256), 0, st, perm[side], side == 0 ? var : left, edge_feats,
                            n_edges, side == 0 ? l_oth : v_oth, side == 0 ? l_coef : v_coef);
         LAUNCHCHK();
-        if (side == 0 && l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+    }
+    if (l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm[0], (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (v2l) {  // by-variable position -> by-left position of the same edge
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[0], n_edges, inv); LAUNCHCHK();
+        hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[1], inv, n_edges, v2l); LAUNCHCHK();
+    }
+    if (l2v) {
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[1], n_edges, inv); LAUNCHCHK();
+        hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[0], inv, n_edges, l2v); LAUNCHCHK();
     }
     return 0;
 }
@@ -1072,43 +1190,39 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
     a.so = so; a.wb = dx2 ? wb : nullptr; a.y2 = dx2; a.beta_y2 = beta2;
     return launch_linear(true, a, (hipStream_t)stream);
 }
-static EdgeArgs edge_args(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const float* p_own,
-                          const float* p_oth, const float* w_edge, const float* e_shift, const float* e_scale,
-                          const float* s1, const float* d_s, float* out, float* dw_partial, int n_own) {
-    EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_own; e.p_oth = p_oth; e.w_edge = w_edge;
-    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.d_s = d_s; e.out = out; e.dw_partial = dw_partial;
-    e.n_recv = n_own;
-    return e;
-}
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
-                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, void* stream) {
+                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out,
+                       void* stream) {
     if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
-    EdgeArgs e = edge_args(seg_ptr, oth, coef, p_recv, p_oth, w_edge, e_shift, e_scale, s1, nullptr, s_out, nullptr, n_recv);
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = (unsigned long long*)mask_out; e.n_recv = n_recv;
     return launch_edge<0>(recv_is_left != 0, e, n_edges, (hipStream_t)stream);
 }
-int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv,
-                            int32_t n_edges, int32_t recv_is_left, const float* p_recv, const float* p_oth,
-                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
-                            const float* d_s, float* d_p_recv, float* dw_partial, void* stream) {
+int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const float* coef, const uint64_t* mask, int32_t n_recv, int32_t n_edges,
+                            const float* e_shift, const float* e_scale, const float* s1, const float* d_s,
+                            float* d_p_recv, float* dw_rows, void* stream) {
     if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
-    if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !d_s || !d_p_recv || !dw_partial)) return GCNN_E_BADARG;
-    if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
-    EdgeArgs e = edge_args(seg_ptr, oth, coef, p_recv, p_oth, w_edge, e_shift, e_scale, s1, d_s, d_p_recv, dw_partial, n_recv);
-    return launch_edge<1>(recv_is_left != 0, e, n_edges, (hipStream_t)stream);
+    if (n_recv > 0 && (!seg_ptr || !e_shift || !e_scale || !s1 || !d_s || !d_p_recv || !dw_rows)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!coef || !mask)) return GCNN_E_BADARG;
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = seg_ptr; e.coef = coef; e.mask = (unsigned long long*)mask; e.e_shift = e_shift; e.e_scale = e_scale;
+    e.s1 = s1; e.d_s = d_s; e.out = d_p_recv; e.dw_rows = dw_rows; e.n_recv = n_recv;
+    return launch_edge<1>(true, e, n_edges, (hipStream_t)stream);
 }
-int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send,
-                            int32_t n_edges, int32_t send_is_left, const float* p_send, const float* p_recv,
-                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
-                            const float* d_s, float* d_p_send, void* stream) {
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const int32_t* xpos, const uint64_t* mask,
+                            int32_t n_send, int32_t n_edges, const float* s1, const float* d_s, float* d_p_send,
+                            void* stream) {
     if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
-    if (n_send > 0 && (!seg_ptr || !p_send || !w_edge || !e_shift || !e_scale || !s1 || !d_p_send)) return GCNN_E_BADARG;
-    if (n_edges > 0 && (!oth || !coef || !p_recv || !d_s)) return GCNN_E_BADARG;
-    EdgeArgs e = edge_args(seg_ptr, oth, coef, p_send, p_recv, w_edge, e_shift, e_scale, s1, d_s, d_p_send, nullptr, n_send);
-    return launch_edge<2>(send_is_left != 0, e, n_edges, (hipStream_t)stream);
+    if (n_send > 0 && (!seg_ptr || !s1 || !d_p_send)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !xpos || !mask || !d_s)) return GCNN_E_BADARG;
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = seg_ptr; e.oth = oth; e.xpos = xpos; e.mask = (unsigned long long*)mask; e.s1 = s1; e.d_s = d_s;
+    e.out = d_p_send; e.n_recv = n_send;
+    return launch_edge<2>(true, e, n_edges, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -1173,6 +1287,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
     float *PL, *PR, *S, *A, *Z1, *OUT;
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
+    unsigned long long* mask;
 };
 
 static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
@@ -1193,7 +1308,7 @@ static int conv_forward(const float* p, const ConvIO& c, hipStream_t st, Tail ta
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
-    e.out = c.S;
+    e.out = c.S; e.mask = c.mask;
     if ((rc = launch_edge<0>(c.recv_left, e, c.ne, st))) return rc;
     Chain ch(nr);
     ChStage& s0 = ch.gemm(c.S, 0, p + poff(c.pbase + C_WF), 0, c.A, 0);           // A = S Wf + deg*bf (K8 hoisted)
@@ -1210,11 +1325,11 @@ static int conv_forward(const float* p, const ConvIO& c, hipStream_t st, Tail ta
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0]};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.mask[0]};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1]};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.mask[1]};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2]};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.mask[2]};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -1319,11 +1434,11 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
-    EdgeArgs e = conv_edge_args(p, c, c.recv_left);
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPL : c.gPR; e.dw_partial = c.Q;
+    EdgeArgs e = conv_edge_args(p, c, c.recv_left);   // receiver-ordered: masks only, no row gathers
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPL : c.gPR; e.dw_rows = c.Q; e.mask = c.mask;
     if ((rc = launch_edge<1>(c.recv_left, e, c.ne, st))) return rc;
-    e = conv_edge_args(p, c, !c.recv_left);   // segments owned by the sender; receiver rows and dS are gathered
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL;
+    e = conv_edge_args(p, c, !c.recv_left);           // sender-ordered: gathers dS rows and the 8-byte masks
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.mask = c.mask; e.xpos = c.recv_left ? c.g->v2l : c.g->l2v;
     if ((rc = launch_edge<2>(!c.recv_left, e, c.ne, st))) return rc;
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
     float* gwe = grads + poff(c.pbase + C_WE);

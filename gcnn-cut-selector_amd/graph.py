@@ -57,6 +57,8 @@ class BipartiteGraph:
         self.v_oth = torch.empty(n_edges, **i32)
         self.l_coef = torch.empty(n_edges, **f32)
         self.v_coef = torch.empty(n_edges, **f32)
+        self.l2v = torch.empty(n_edges, **i32)   # by-left position -> by-variable position of the same edge
+        self.v2l = torch.empty(n_edges, **i32)
         self.l_perm = torch.empty(n_edges, **i32) if keep_perm else None
         lib = _lib.lib()
         temp_bytes = lib.gcnn_graph_temp_bytes(n_edges)
@@ -64,10 +66,12 @@ class BipartiteGraph:
         with torch.cuda.device(dev):
             _lib.check(lib.gcnn_graph_build(_ptr(edge_inds), _ptr(edge_feats), n_edges, n_left, n_var,
                                             _ptr(self.l_ptr), _ptr(self.l_oth), _ptr(self.l_coef), _ptr(self.v_ptr),
-                                            _ptr(self.v_oth), _ptr(self.v_coef), _ptr(self.l_perm), _ptr(temp),
+                                            _ptr(self.v_oth), _ptr(self.v_coef), _ptr(self.l2v), _ptr(self.v2l),
+                                            _ptr(self.l_perm), _ptr(temp),
                                             temp_bytes, _stream(dev)), "gcnn_graph_build")
         # keep the temp alive until the stream has consumed it
         temp.record_stream(torch.cuda.current_stream(dev))
         self.c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
                             self.l_coef.data_ptr() if n_edges else 0, self.v_ptr.data_ptr(),
-                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0)
+                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0,
+                            self.l2v.data_ptr() if n_edges else 0, self.v2l.data_ptr() if n_edges else 0)

@@ -46,6 +46,8 @@ typedef struct gcnn_graph {
     const int32_t* v_ptr;   /* [n_var+1]   segment offsets, edges grouped by variable node */
     const int32_t* v_oth;   /* [E]         left index of each edge, by-variable order */
     const float*   v_coef;  /* [E]         raw edge feature, by-variable order */
+    const int32_t* l2v;     /* [E]         by-left position -> by-variable position of the same edge */
+    const int32_t* v2l;     /* [E]         by-variable position -> by-left position of the same edge */
 } gcnn_graph;
 
 /* ---- graph plan: COO -> receiver-sorted CSR in both orders -------------------------------------------------
@@ -56,8 +58,9 @@ typedef struct gcnn_graph {
 size_t gcnn_graph_temp_bytes(int32_t n_edges);
 int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left,
                      int32_t n_var, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
-                     float* v_coef, int32_t* l_perm /* optional [E]: by-left position -> input edge id */,
-                     void* temp, size_t temp_bytes, void* stream);
+                     float* v_coef, int32_t* l2v /* optional */, int32_t* v2l /* optional */,
+                     int32_t* l_perm /* optional [E]: by-left position -> input edge id */, void* temp, size_t temp_bytes,
+                     void* stream);
 
 /* ---- standalone scatter-sum pass (K9): tf.scatter_nd(updates=[E,64], indices, shape=[R,64]), model.py:568-569
  * seg_ptr[R+1] are receiver-sorted segment offsets; perm (optional) maps sorted position -> row of `msg`
@@ -84,20 +87,21 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * ((PL[l_e] + c_e*w_edge) + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
  *           p_recv = projected table of the receiving side [n_recv,64], p_oth = the other side's table, gathered by
  *           oth[e]; recv_is_left: receiver is the constraint/cut side (from_v=True, model.py:553-556).
- * bwd_recv: d_p_recv[r] = sum_e dJ_e, dJ_e = s1*d_s[r]*[s1*J_e > 0]; dw_rows: [n_recv,64], row r = sum_{e in seg(r)} c_e dJ_e,
- *           this receiver's share of d w_edge (its column sum is the gradient of feature_module_edge, model.py:490-492).
- * bwd_send: segments grouped by the SENDING node: d_p_send[u] = sum_{e in seg(u)} s1*d_s[oth_e]*[s1*J_e > 0]. */
+ *           mask_out (optional, [E] uint64, receiver order): bit 16*k+c of word e = [s1*J_e > 0] for channel 4*c+k.
+ * bwd_recv: receiver order, no row gathers: d_p_recv[r] = s1*d_s[r]*popcount_e(mask), dw_rows[r] = s1*d_s[r]*sum_e c_e*mask_e
+ *           (dw_rows' column sum is the gradient of feature_module_edge's kernel, model.py:490-492).
+ * bwd_send: segments grouped by the SENDING node: d_p_send[u] = s1 * sum_{e in seg(u)} mask[xpos[e]] * d_s[oth[e]];
+ *           xpos[e] = position of edge e in the receiver-ordered list (gcnn_graph.l2v / v2l). */
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
-                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, void* stream);
-int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv,
-                            int32_t n_edges, int32_t recv_is_left, const float* p_recv, const float* p_oth,
-                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
+                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out,
+                       void* stream);
+int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const float* coef, const uint64_t* mask, int32_t n_recv,
+                            int32_t n_edges, const float* e_shift, const float* e_scale, const float* s1,
                             const float* d_s, float* d_p_recv, float* dw_rows, void* stream);
-int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send,
-                            int32_t n_edges, int32_t send_is_left, const float* p_send, const float* p_recv,
-                            const float* w_edge, const float* e_shift, const float* e_scale, const float* s1,
-                            const float* d_s, float* d_p_send, void* stream);
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const int32_t* xpos, const uint64_t* mask,
+                            int32_t n_send, int32_t n_edges, const float* s1, const float* d_s, float* d_p_send,
+                            void* stream);
 
 /* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
  * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied
