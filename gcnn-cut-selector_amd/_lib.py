@@ -44,11 +44,11 @@ SIGNATURES = {
     "gcnn_seg_bcast_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
     "gcnn_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     "gcnn_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
-    "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _P, _P]),
+    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gcnn_workspace_floats": (_Z, [_DP]),
-    "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P]),
+    "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _I, _P]),
     "gcnn_mse_loss": (C.c_int, [_P, _P, _I, _F, _P, _P, _P]),
     "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P]),
     "gcnn_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),

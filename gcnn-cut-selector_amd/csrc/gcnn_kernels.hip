@@ -313,11 +313,8 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
 // Fused row chains.  Every node-side layer of the model is row-local (a 16-row tile of a [N,64] matrix goes through
 // a sequence of 64x64 products with element-wise epilogues), so a whole sequence -- e.g. S -> A -> Z1 -> X' -> PL'
 // of one PartialGraphConvolution (model.py:498-508, 570-573) or its gradient -- runs in ONE launch: each wave owns
-// 16-row tiles, keeps the running tile in LDS (2 tiles per wave), reads every weight of the chain from LDS
-// (staged once per block) and stores only the tensors the backward pass / the next edge pass need.
-// MFMA: v_mfma_f32_16x16x4_f32, 4 independent accumulators (the four 16-column tiles of the output).  The k index is
-// split across the four 16-lane groups (group g takes k in [16g, 16g+16)), so the 64 products of a dot product are
-// added in the order 0,16,32,48,1,17,... (exact fp32 FMA chain).
+// 16-row tiles, reads every weight of the chain from LDS (staged once per block) and stores only the tensors the
+// backward pass / the next edge pass need.  MFMA: v_mfma_f32_16x16x4_f32, 4 independent accumulators.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -339,152 +336,212 @@ struct ChStage {
     const float* so; const float* bias; const float* bd; const int* seg_ptr; const float* add; const float* mask;
     int relu;
     float* out; int tout;             // global store (optional) and the LDS tile that keeps the result
+    // optional element-wise side output of the result v:  em_out = *em_s * v * em_a
+    const float* em_s; const float* em_a; float* em_out;
     // CH_EMBED1: x_raw [N,F], PreNorm shift/scale [F], kernel [F,64] (global), bias via `bias`
     const float* x_raw; const float* shift; const float* scale; const float* w1; int nfeat;
     // CH_SCORE: out[r] = tile(ta)[r] . w1[0:64] + *bias
 };
 struct ChArgs { int n; int nstage; int nw; const float* w[CH_MAX_W]; ChStage st[CH_MAX_STAGES]; };
 
-__device__ __forceinline__ void ch_load_tile(float* t, const float* __restrict__ x, int row0, int n, int lane) {
+// Register-resident chains.  Each stage computes the TRANSPOSED product  Y^T[64 x 16 rows] = Wop[64 x 64] . X^T  with the
+// weights as the MFMA A operand (read from LDS, independent of the data, so the reads run ahead) and the activation
+// tile as the B operand.  With that orientation the accumulator of one stage IS the B operand of the next one:
+//   lane (j = lane&15, g = lane>>4) holds, for each 16-feature block mt and i = 0..3, the element
+//   X[row0 + j][16*mt + 4*g + i]   -- as B operand of k-step (mt, i) (the instruction's k index is g), and as C/D
+//   layout of the output block mo (rows of D = features 4*g + i of block mo, column = row j of the tile).
+// So a whole chain runs without any LDS round trip for activations; global rows are read/written as float4 pieces
+// X[row][16*mt + 4*g .. +3] straight from/to that layout.  The direction (x@W forward / x@W^T backward) is a
+// compile-time parameter; the stage program itself is data (ChArgs).
+struct RTile { float v[4][4]; };
+
+__device__ __forceinline__ void rt_zero(RTile& t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = i * 4 + (lane >> 4), c = (lane & 15) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < n) v = *(const float4*)(x + (size_t)(row0 + r) * EMB + c);
-        *(float4*)(t + r * LDW + c) = v;
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.v[m][i] = 0.f;
+}
+__device__ __forceinline__ void rt_load(RTile& t, const float* __restrict__ x, int row, bool ok, int g) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) f = *(const float4*)(x + (size_t)row * EMB + 16 * m + 4 * g);
+        t.v[m][0] = f.x; t.v[m][1] = f.y; t.v[m][2] = f.z; t.v[m][3] = f.w;
     }
 }
+__device__ __forceinline__ void rt_store(const RTile& t, float* __restrict__ x, int row, bool ok, int g) {
+    if (!ok) return;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        *(float4*)(x + (size_t)row * EMB + 16 * m + 4 * g) = make_float4(t.v[m][0], t.v[m][1], t.v[m][2], t.v[m][3]);
+}
 
+// acc[mo] += Wop[16*mo + (lane&15)][kf] * T[kf], kf = 16*mt + 4*g + i;  NN: Wop[o][k] = W[k][o],  TN: Wop[o][k] = W[o][k]
 template <bool TRANSB>
-__device__ __forceinline__ void ch_gemm(const float* t, const float* wl, float sa, f32x4 (&acc)[4], int lane) {
-    const int r = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void rt_gemm(const RTile& t, float scale, const float* wl, f32x4 (&acc)[4], int lane) {
+    const int m = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 a4 = *(const float4*)(t + r * LDW + 16 * g + 4 * q);
-        const float av[4] = {a4.x * sa, a4.y * sa, a4.z * sa, a4.w * sa};
+    for (int mt = 0; mt < 4; ++mt) {
+        float av[4][4];  // [mo][i]
         if (TRANSB) {
-            float bv[4][4];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const float4 b4 = *(const float4*)(wl + (ct * 16 + r) * LDW + 16 * g + 4 * q);
-                bv[ct][0] = b4.x; bv[ct][1] = b4.y; bv[ct][2] = b4.z; bv[ct][3] = b4.w;
+            for (int mo = 0; mo < 4; ++mo) {
+                const float4 w4 = *(const float4*)(wl + (16 * mo + m) * LDW + 16 * mt + 4 * g);
+                av[mo][0] = w4.x; av[mo][1] = w4.y; av[mo][2] = w4.z; av[mo][3] = w4.w;
             }
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av[tt], bv[ct][tt], acc[ct]);
         } else {
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int k = 16 * g + 4 * q + tt;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av[tt], wl[k * LDW + ct * 16 + r], acc[ct]);
-            }
+                for (int mo = 0; mo < 4; ++mo) av[mo][i] = wl[(16 * mt + 4 * g + i) * LDW + 16 * mo + m];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float b = t.v[mt][i] * scale;
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) acc[mo] = mfma16(av[mo][i], b, acc[mo]);
         }
     }
 }
 
-template <int NWAVES>
+#define CH_PAR 144  // per-stage LDS parameter block: bias[64], bd[64], {sa, so, es, score bias}, padding
+template <int NWAVES, bool TRANSB>
 __global__ __launch_bounds__(NWAVES * 64) void k_chain(ChArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* tiles = smem + a.nw * 64 * LDW + wv * 2 * CH_TILE;
-    // stage the chain's weights: [nw][64][LDW]
-    for (int idx = threadIdx.x; idx < a.nw * 1024; idx += NWAVES * 64) {
-        const int wi = idx >> 10, r = (idx >> 4) & 63, c = (idx & 15) * 4;
-        *(float4*)(smem + wi * 64 * LDW + r * LDW + c) = *(const float4*)(a.w[wi] + r * EMB + c);
+    const int j = lane & 15, g = lane >> 4;
+    const int ntile = (a.n + 15) >> 4;
+    const int tile0 = blockIdx.x * NWAVES + wv;
+    float* par = smem + a.nw * 64 * LDW;
+
+    // per-stage bias vectors and scalars go to LDS next to the weights (one dependent global read, once per block)
+    for (int s = 0; s < a.nstage; ++s) {
+        const ChStage& st = a.st[s];
+        if (threadIdx.x < 128) {
+            const float* src = threadIdx.x < 64 ? st.bias : st.bd;
+            const int col = threadIdx.x & 63;
+            par[s * CH_PAR + threadIdx.x] = (src && st.type != CH_SCORE) ? src[col] : 0.f;
+        } else if (threadIdx.x < 132) {
+            const int k = threadIdx.x - 128;
+            const float* src = k == 0 ? st.sa : (k == 1 ? st.so : (k == 2 ? st.em_s : (st.type == CH_SCORE ? st.bias : nullptr)));
+            par[s * CH_PAR + threadIdx.x] = src ? *src : (k == 3 ? 0.f : 1.f);
+        }
+    }
+    // first tile's stage-0 input rows: issue the loads before the weights so the latencies overlap
+    RTile pre;
+    const bool have_pre = a.st[0].type == CH_GEMM && a.st[0].in_a != nullptr;
+    rt_load(pre, a.st[0].in_a, tile0 * 16 + j, have_pre && tile0 * 16 + j < a.n, g);
+    // stage the chain's weights: [nw][64][LDW], a batch of loads in flight per thread
+    for (int wi = 0; wi < a.nw; ++wi) {
+        const float* __restrict__ wsrc = a.w[wi];
+        float* wdst = smem + wi * 64 * LDW;
+        constexpr int PER = 1024 / (NWAVES * 64);  // float4 per thread per matrix: 4 (256 threads) or 2 (512)
+        float4 tmp[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tmp[i] = *(const float4*)(wsrc + (size_t)(i * NWAVES * 64 + threadIdx.x) * 4);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NWAVES * 64 + threadIdx.x;
+            *(float4*)(wdst + (idx >> 4) * LDW + (idx & 15) * 4) = tmp[i];
+        }
     }
     __syncthreads();
 
-    const int ntile = (a.n + 15) >> 4;
-    for (int tile = blockIdx.x * NWAVES + wv; tile < ntile; tile += gridDim.x * NWAVES) {
-        const int row0 = tile * 16;
+    for (int tile = tile0; tile < ntile; tile += gridDim.x * NWAVES) {
+        const int row = tile * 16 + j;
+        const bool ok = row < a.n;
+        RTile t0, t1;   // the two register tiles stages read from / write to (ChStage.ta / tb / tout)
+        rt_zero(t0); rt_zero(t1);
+#pragma unroll 1
         for (int s = 0; s < a.nstage; ++s) {
             const ChStage& st = a.st[s];
-            float* tout = tiles + st.tout * CH_TILE;
-            if (st.type == CH_SCORE) {
-                const float* t = tiles + st.ta * CH_TILE;
-                const int r = lane >> 2, q = lane & 3;
+            const float* ps = par + s * CH_PAR;
+            if (!TRANSB && st.type == CH_SCORE) {   // closes a forward chain: Dense(64->1), model.py:208
                 float sum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 v = *(const float4*)(t + r * LDW + q * 16 + i * 4);
-                    const float4 w = *(const float4*)(st.w1 + q * 16 + i * 4);
-                    sum = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, sum))));
+                for (int m = 0; m < 4; ++m) {
+                    const float4 w = *(const float4*)(st.w1 + 16 * m + 4 * g);
+                    const float* tv = st.ta ? t1.v[m] : t0.v[m];
+                    sum = fmaf(tv[0], w.x, fmaf(tv[1], w.y, fmaf(tv[2], w.z, fmaf(tv[3], w.w, sum))));
                 }
-                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-                if (q == 0 && row0 + r < a.n) st.out[row0 + r] = sum + *st.bias;
+                sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+                if (g == 0 && ok) st.out[row] = sum + ps[131];
                 continue;
             }
-            if (st.type == CH_EMBED1) {
-                // relu(((x + shift) * scale) @ W1 + b1): lane = (row, 16-column group), K <= 16 on the VALU
-                const int r = lane & 15, cg = (lane >> 4) * 16;
-                float accv[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) accv[c] = 0.f;
-                const bool ok = row0 + r < a.n;
+            // operands of this stage: issue the global loads now, consume them after the MFMAs
+            RTile r_inb, r_add, r_mask, r_em;
+            rt_load(r_inb, st.in_b, row, ok && st.in_b != nullptr, g);
+            rt_load(r_add, st.add, row, ok && st.add != nullptr, g);
+            rt_load(r_mask, st.mask, row, ok && st.mask != nullptr, g);
+            rt_load(r_em, st.em_a, row, ok && st.em_a != nullptr, g);
+            float deg = 0.f;
+            if (st.bd && ok) deg = (float)(st.seg_ptr[row + 1] - st.seg_ptr[row]);
+            const float sa = ps[128], so = ps[129], es = ps[130];
+
+            RTile o;
+            if (!TRANSB && st.type == CH_EMBED1) {   // opens a forward chain
+                // ((x + shift) * scale) @ W1 on the VALU (K <= 16); bias and ReLU come with the common epilogue
+                rt_zero(o);
                 for (int f = 0; f < st.nfeat; ++f) {
-                    const float xv = ok ? (st.x_raw[(size_t)(row0 + r) * st.nfeat + f] + st.shift[f]) * st.scale[f] : 0.f;
+                    const float xv = ok ? (st.x_raw[(size_t)row * st.nfeat + f] + st.shift[f]) * st.scale[f] : 0.f;
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const float4 w = *(const float4*)(st.w1 + f * EMB + cg + c4 * 4);
-                        accv[c4 * 4 + 0] = fmaf(xv, w.x, accv[c4 * 4 + 0]); accv[c4 * 4 + 1] = fmaf(xv, w.y, accv[c4 * 4 + 1]);
-                        accv[c4 * 4 + 2] = fmaf(xv, w.z, accv[c4 * 4 + 2]); accv[c4 * 4 + 3] = fmaf(xv, w.w, accv[c4 * 4 + 3]);
+                    for (int m = 0; m < 4; ++m) {
+                        const float4 w = *(const float4*)(st.w1 + f * EMB + 16 * m + 4 * g);
+                        o.v[m][0] = fmaf(xv, w.x, o.v[m][0]); o.v[m][1] = fmaf(xv, w.y, o.v[m][1]);
+                        o.v[m][2] = fmaf(xv, w.z, o.v[m][2]); o.v[m][3] = fmaf(xv, w.w, o.v[m][3]);
                     }
                 }
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4)
-                    *(float4*)(tout + r * LDW + cg + c4 * 4) = make_float4(accv[c4 * 4], accv[c4 * 4 + 1], accv[c4 * 4 + 2], accv[c4 * 4 + 3]);
             } else {
                 f32x4 acc[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float* ta = tiles + st.ta * CH_TILE;
-                if (st.in_a) ch_load_tile(ta, st.in_a, row0, a.n, lane);
-                const float sa = st.sa ? *st.sa : 1.f;
-                const float* wl = smem + st.wa * 64 * LDW;
-                if (st.transb) ch_gemm<true>(ta, wl, sa, acc, lane); else ch_gemm<false>(ta, wl, sa, acc, lane);
-                if (st.in_b) {
-                    float* tb = tiles + st.tb * CH_TILE;
-                    ch_load_tile(tb, st.in_b, row0, a.n, lane);
-                    const float* wl2 = smem + st.wb * 64 * LDW;
-                    if (st.transb) ch_gemm<true>(tb, wl2, 1.f, acc, lane); else ch_gemm<false>(tb, wl2, 1.f, acc, lane);
+                for (int mo = 0; mo < 4; ++mo) acc[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                RTile in;
+                if (st.in_a) {
+                    if (s == 0 && tile == tile0) in = pre; else rt_load(in, st.in_a, row, ok, g);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) in.v[m][i] = st.ta ? t1.v[m][i] : t0.v[m][i];
                 }
-                const float so = st.so ? *st.so : 1.f;
-                const int j = lane & 15, g = lane >> 4;
+                rt_gemm<TRANSB>(in, sa, smem + st.wa * 64 * LDW, acc, lane);
+                if (st.in_b) rt_gemm<TRANSB>(r_inb, 1.f, smem + st.wb * 64 * LDW, acc, lane);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
+                for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tout[(4 * g + i) * LDW + ct * 16 + j] = acc[ct][i] * so;
+                    for (int i = 0; i < 4; ++i) o.v[mo][i] = acc[mo][i] * so;
             }
-            // row pass over the output tile: full 256-B lines, 16 B per lane
-            const int c = (lane & 15) * 4;
-            float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), bd = bias;
-            if (st.bias) bias = *(const float4*)(st.bias + c);
-            if (st.bd) bd = *(const float4*)(st.bd + c);
+            // epilogue in registers: +bias, +deg*bd, +add, relu, *(mask > 0)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = i * 4 + (lane >> 4), gr = row0 + r;
-                float4 v = *(const float4*)(tout + r * LDW + c);
-                const bool ok = gr < a.n;
-                v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-                if (st.bd && ok) {
-                    const float deg = (float)(st.seg_ptr[gr + 1] - st.seg_ptr[gr]);
-                    v.x = fmaf(deg, bd.x, v.x); v.y = fmaf(deg, bd.y, v.y); v.z = fmaf(deg, bd.z, v.z); v.w = fmaf(deg, bd.w, v.w);
+            for (int m = 0; m < 4; ++m) {
+                const float4 bias = *(const float4*)(ps + 16 * m + 4 * g);
+                const float4 bd = *(const float4*)(ps + 64 + 16 * m + 4 * g);
+                const float bv[4] = {bias.x, bias.y, bias.z, bias.w}, dv[4] = {bd.x, bd.y, bd.z, bd.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = o.v[m][i] + bv[i];
+                    v = fmaf(deg, dv[i], v);
+                    v += r_add.v[m][i];
+                    if (st.relu) v = fmaxf(v, 0.f);
+                    if (st.mask) v = r_mask.v[m][i] > 0.f ? v : 0.f;
+                    o.v[m][i] = ok ? v : 0.f;
                 }
-                if (st.add && ok) {
-                    const float4 o = *(const float4*)(st.add + (size_t)gr * EMB + c);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                if (st.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (st.mask && ok) {
-                    const float4 m = *(const float4*)(st.mask + (size_t)gr * EMB + c);
-                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-                }
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *(float4*)(tout + r * LDW + c) = v;
-                if (st.out && ok) *(float4*)(st.out + (size_t)gr * EMB + c) = v;
             }
+            if (st.out) rt_store(o, st.out, row, ok, g);
+            if (st.em_out) {
+                RTile e;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e.v[m][i] = es * o.v[m][i] * r_em.v[m][i];
+                rt_store(e, st.em_out, row, ok, g);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (st.tout) t1.v[m][i] = o.v[m][i]; else t0.v[m][i] = o.v[m][i];
+                }
         }
     }
 }
@@ -597,23 +654,23 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Edge pass (K5-K7 + K9 fused, K8 hoisted): S[r] = sum_{e in seg(r)} relu(s1 * ((PL[l_e] + c_e*w) + PR[v_e]))
+// Edge pass (K5-K7 + K9 fused, K8 hoisted): S[r] = sum_{e in seg(r)} relu(s1 * (PL[l_e] + c_e*w + PR[v_e]))
 // with c_e = (coef_e + e_shift) * e_scale (the edge PreNorm, model.py:288/291).
 // G = 16*SLOTS lanes cooperate on one receiver: 16 lanes x float4 cover the 64 channels, SLOTS edges in flight per
 // step and 4 steps unrolled => up to 4*SLOTS independent 256-B row gathers per receiver.  The segment's (index, coef)
-// pairs are loaded coalesced, one per lane, and broadcast with wave shuffles.  Slot partial sums are combined in a
-// fixed order.  OWNER_LEFT: the node that owns the segment is the left node (constraint/cut) -- the receiver of
-// conv v->c / v->k (model.py:553-556) in MODE 0/1, the sender of conv c->v in MODE 2.
+// pairs are loaded coalesced, one per lane, and broadcast with wave shuffles (loops have group-uniform trip counts: a
+// shuffle must never read a lane that has left the loop).  Slot partial sums are combined in a fixed order.
 // ---------------------------------------------------------------------------------------------------------------
 struct EdgeArgs {
     const int* seg_ptr; const int* oth; const float* coef;
     const float* p_recv; const float* p_oth;      // forward: projected tables of the segment owner [R,64] / the gathered side
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
-    const float* d_s;                              // backward: dS [R,64] (own row in the recv pass, gathered in the send pass)
+    const float* d_s;                              // send pass: dS [R,64], gathered by oth
     const int* xpos;                               // send pass: position of each edge in the receiver-ordered list
-    unsigned long long* mask;                      // [E] ReLU masks in receiver order: written by forward, read by backward
-    float* out;                                    // S (fwd) / dP_recv / dP_send
-    float* dw_rows;                                // recv pass: Q [R,64], per-receiver share of d w_edge
+    unsigned char* mask;                           // [E][16] ReLU nibbles in receiver order: written by forward, read by send pass
+    float* out;                                    // S (fwd) / dP_send
+    float* dw_rows;                                // send pass: Q [n_send,64], per-sender share of d w_edge
+    float* cnt_rows;                               // fwd (SAVE): N[r] = number of active edges per channel
     int n_recv;
 };
 
@@ -628,20 +685,19 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
     return v;
 }
 
-// The 64 ReLU bits of one edge: bit (16*k + c) belongs to channel 4*c + k (lane c of the 16-lane group, component k).
-__device__ __forceinline__ float4 mask_bits(unsigned lo, unsigned hi, int c) {
-    return make_float4((float)((lo >> c) & 1u), (float)((lo >> (16 + c)) & 1u), (float)((hi >> c) & 1u),
-                       (float)((hi >> (16 + c)) & 1u));
-}
-
-// Forward.  OWNER_LEFT: the receiver is the left node (constraint/cut; from_v=True, model.py:553-556).
-template <int SLOTS, bool OWNER_LEFT>
-__global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
+// Forward edge pass.  relu(s1*J) = s1*max(J,0) for s1 >= 0 and s1*min(J,0) for s1 < 0, so the scale is applied once per
+// receiver.  J_e = (c_e*w + P_oth[oth_e]) + P_own[r].
+// SAVE also emits what the backward pass needs: per edge 16 bytes (lane c of the edge's 16-lane group stores the ReLU
+// bits of its channels 4c..4c+3 as a nibble) and per receiver/channel the number N of active edges.  Because dS[r] is
+// constant over a receiver's segment, dP_recv[r] = s1*dS[r]*N[r]: the receiver-ordered half of the backward pass is an
+// element-wise epilogue (of the chain that produces dS), not an edge pass.
+template <int SLOTS, bool SAVE, bool NEG>
+__device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, ch = (gl & 15) * 4, q16 = (lane >> 4) * 16;
+    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
     const float4 w = *(const float4*)(a.w_edge + ch);
-    const float esh = *a.e_shift, esc = *a.e_scale, s1 = *a.s1;
+    const float esh = *a.e_shift, esc = *a.e_scale;
 
     const int nwork = (a.n_recv + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
@@ -650,6 +706,7 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
             const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
             const float4 pown = *(const float4*)(a.p_recv + (size_t)r * EMB + ch);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             for (int base = beg; base < end; base += G) {
                 const int e = base + gl;
                 int o = 0; float c = 0.f;
@@ -665,131 +722,103 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
                         oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < 4; ++u)
                         if (ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
-                    }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const float cw[4] = {__fmul_rn(ci[u], w.x), __fmul_rn(ci[u], w.y), __fmul_rn(ci[u], w.z),
-                                             __fmul_rn(ci[u], w.w)};
-                        const float pw[4] = {pown.x, pown.y, pown.z, pown.w};
-                        const float po[4] = {p[u].x, p[u].y, p[u].z, p[u].w};
-                        float hj[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            hj[k] = s1 * (OWNER_LEFT ? jointf(pw[k], cw[k], po[k]) : jointf(po[k], cw[k], pw[k]));
-                            hj[k] = ok[u] ? fmaxf(hj[k], 0.f) : 0.f;
-                        }
-                        acc.x += hj[0]; acc.y += hj[1]; acc.z += hj[2]; acc.w += hj[3];
-                        if (a.mask) {  // 4 ballots = the 64 bits of each of the (up to) four edges this wave just did
-                            const unsigned long long b0 = __ballot(hj[0] > 0.f), b1 = __ballot(hj[1] > 0.f);
-                            const unsigned long long b2 = __ballot(hj[2] > 0.f), b3 = __ballot(hj[3] > 0.f);
-                            if (ok[u] && (lane & 15) == 0)
-                                a.mask[base + i0 + u * SLOTS + slot] =
-                                    ((b0 >> q16) & 0xffffull) | (((b1 >> q16) & 0xffffull) << 16) |
-                                    (((b2 >> q16) & 0xffffull) << 32) | (((b3 >> q16) & 0xffffull) << 48);
+                        if (ok[u]) {
+                            float h0 = fmaf(ci[u], w.x, p[u].x) + pown.x, h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
+                            float h2 = fmaf(ci[u], w.z, p[u].z) + pown.z, h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
+                            h0 = NEG ? fminf(h0, 0.f) : fmaxf(h0, 0.f); h1 = NEG ? fminf(h1, 0.f) : fmaxf(h1, 0.f);
+                            h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
+                            acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
+                            if (SAVE) {
+                                const int b0 = h0 != 0.f, b1 = h1 != 0.f, b2 = h2 != 0.f, b3 = h3 != 0.f;
+                                n0 += b0; n1 += b1; n2 += b2; n3 += b3;
+                                a.mask[(size_t)(base + i0 + u * SLOTS + slot) * 16 + cl] = (unsigned char)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3));
+                            }
                         }
                     }
                 }
             }
             acc = slot_reduce<SLOTS>(acc);
-            if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = acc;
-        }
-    }
-}
-
-// Backward, receiver-ordered: dJ_e = s1 * dS[r] * mask_e, so with dS[r] constant over the segment
-//   dP_recv[r] = s1 * dS[r] * (#set bits per channel),   Q[r] = s1 * dS[r] * sum_e c_e * mask_e   (no row gathers)
-template <int SLOTS>
-__global__ __launch_bounds__(256) void k_edge_bwd_recv(EdgeArgs a) {
-    constexpr int G = 16 * SLOTS, RPW = 64 / G;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
-    const float esh = *a.e_shift, esc = *a.e_scale, s1 = *a.s1;
-    const int nwork = (a.n_recv + RPW - 1) / RPW;
-    for (int item = blockIdx.x * 4 + wv; item < nwork; item += gridDim.x * 4) {
-        const int r = item * RPW + lane / G;
-        if (r < a.n_recv) {
-            const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
-            const float4 ds = *(const float4*)(a.d_s + (size_t)r * EMB + ch);
-            float4 cnt4 = make_float4(0.f, 0.f, 0.f, 0.f), cw4 = cnt4;
-            for (int base = beg; base < end; base += G) {
-                const int e = base + gl;
-                unsigned lo = 0, hi = 0; float c = 0.f;
-                if (e < end) {
-                    const unsigned long long m = a.mask[e];
-                    lo = (unsigned)m; hi = (unsigned)(m >> 32); c = (a.coef[e] + esh) * esc;
-                }
-                const int cnt = min(G, end - base);
-                for (int i0 = 0; i0 < cnt; i0 += SLOTS) {  // group-uniform trip count: a shuffle must not read an exited lane
-                    const int i = i0 + slot;
-                    const bool ok = i < cnt;
-                    const int src = gbase + (ok ? i : 0);
-                    float4 b = mask_bits(__shfl(lo, src), __shfl(hi, src), cl);
-                    if (!ok) b = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float ci = __shfl(c, src);
-                    cnt4.x += b.x; cnt4.y += b.y; cnt4.z += b.z; cnt4.w += b.w;
-                    cw4.x = fmaf(ci, b.x, cw4.x); cw4.y = fmaf(ci, b.y, cw4.y); cw4.z = fmaf(ci, b.z, cw4.z); cw4.w = fmaf(ci, b.w, cw4.w);
-                }
-            }
-            cnt4 = slot_reduce<SLOTS>(cnt4); cw4 = slot_reduce<SLOTS>(cw4);
-            if (slot == 0) {
-                const float4 sd = make_float4(s1 * ds.x, s1 * ds.y, s1 * ds.z, s1 * ds.w);
-                *(float4*)(a.out + (size_t)r * EMB + ch) = make_float4(sd.x * cnt4.x, sd.y * cnt4.y, sd.z * cnt4.z, sd.w * cnt4.w);
-                *(float4*)(a.dw_rows + (size_t)r * EMB + ch) = make_float4(sd.x * cw4.x, sd.y * cw4.y, sd.z * cw4.z, sd.w * cw4.w);
+            if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
+            if (SAVE) {
+                const float4 nacc = slot_reduce<SLOTS>(make_float4((float)n0, (float)n1, (float)n2, (float)n3));
+                if (slot == 0) *(float4*)(a.cnt_rows + (size_t)r * EMB + ch) = nacc;
             }
         }
     }
 }
 
-// Backward, sender-ordered: dP_send[u] = s1 * sum_{e in seg(u)} mask_e * dS[recv(e)]: one 256-B row gather and one 8-B
-// mask gather (through xpos, the edge's position in the receiver-ordered list) per edge.
+template <int SLOTS, bool SAVE>
+__global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
+    const float s1 = *a.s1;
+    if (s1 < 0.f) edge_fwd_impl<SLOTS, SAVE, true>(a, s1); else edge_fwd_impl<SLOTS, SAVE, false>(a, s1);
+}
+
+// Backward, receiver-ordered half, element-wise: dP_recv[r] = s1*dS[r]*N[r].  (The model fuses this into the epilogue of
+// the chain that produces dS; this kernel serves the per-op entry point.)
+__global__ __launch_bounds__(256) void k_edge_bwd_recv(const float* __restrict__ d_s, const float* __restrict__ nrows,
+                                                       const float* __restrict__ s1p, float* __restrict__ d_p, int n4) {
+    const float s1 = *s1p;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const float4 d = ((const float4*)d_s)[i], nn = ((const float4*)nrows)[i];
+        ((float4*)d_p)[i] = make_float4(s1 * d.x * nn.x, s1 * d.y * nn.y, s1 * d.z * nn.z, s1 * d.w * nn.w);
+    }
+}
+
+// Backward, sender-ordered half: with t_e = mask_e * dS[recv(e)],
+//   dP_send[u] = s1 * sum_{e in seg(u)} t_e          Q[u] = s1 * sum_{e in seg(u)} c_e * t_e   (share of d w_edge)
+// one 256-B row gather and one 16-B mask gather (through xpos, the edge's position in the receiver-ordered list) per edge.
 template <int SLOTS>
 __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
-    const float s1 = *a.s1;
+    const float s1 = *a.s1, esh = *a.e_shift, esc = *a.e_scale;
     const int nwork = (a.n_recv + RPW - 1) / RPW;
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
         const int u = item * RPW + lane / G;
         if (u < a.n_recv) {
             const int beg = a.seg_ptr[u], end = a.seg_ptr[u + 1];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
             for (int base = beg; base < end; base += G) {
                 const int e = base + gl;
-                int o = 0; unsigned lo = 0, hi = 0;
-                if (e < end) {
-                    o = a.oth[e];
-                    const unsigned long long m = a.mask[a.xpos[e]];
-                    lo = (unsigned)m; hi = (unsigned)(m >> 32);
-                }
+                int o = 0, xp = 0; float c = 0.f;
+                if (e < end) { o = a.oth[e]; xp = a.xpos[e]; c = (a.coef[e] + esh) * esc; }
                 const int cnt = min(G, end - base);
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; bool ok[4]; float4 b[4], d[4];
+                    int oi[4], xi[4]; float ci[4]; bool ok[4]; float4 d[4]; unsigned mb[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int i = i0 + v * SLOTS + slot;
                         ok[v] = i < cnt;
                         const int src = gbase + (ok[v] ? i : 0);
-                        oi[v] = __shfl(o, src);
-                        b[v] = mask_bits(__shfl(lo, src), __shfl(hi, src), cl);
+                        oi[v] = __shfl(o, src); xi[v] = __shfl(xp, src); ci[v] = __shfl(c, src);
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        d[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (ok[v]) d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
+                        mb[v] = 0u; d[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok[v]) {
+                            d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
+                            mb[v] = a.mask[(size_t)xi[v] * 16 + cl];
+                        }
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        acc.x = fmaf(b[v].x, d[v].x, acc.x); acc.y = fmaf(b[v].y, d[v].y, acc.y);
-                        acc.z = fmaf(b[v].z, d[v].z, acc.z); acc.w = fmaf(b[v].w, d[v].w, acc.w);
+                        const float t0 = (mb[v] & 1u) ? d[v].x : 0.f, t1 = (mb[v] & 2u) ? d[v].y : 0.f;
+                        const float t2 = (mb[v] & 4u) ? d[v].z : 0.f, t3 = (mb[v] & 8u) ? d[v].w : 0.f;
+                        acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
+                        dw.x = fmaf(ci[v], t0, dw.x); dw.y = fmaf(ci[v], t1, dw.y); dw.z = fmaf(ci[v], t2, dw.z); dw.w = fmaf(ci[v], t3, dw.w);
                     }
                 }
             }
-            acc = slot_reduce<SLOTS>(acc);
-            if (slot == 0) *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
+            acc = slot_reduce<SLOTS>(acc); dw = slot_reduce<SLOTS>(dw);
+            if (slot == 0) {
+                *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
+                *(float4*)(a.dw_rows + (size_t)u * EMB + ch) = make_float4(s1 * dw.x, s1 * dw.y, s1 * dw.z, s1 * dw.w);
+            }
         }
     }
 }
@@ -994,23 +1023,27 @@ static inline int edge_slots(int n_own, int n_edges) {
     const double avg = (double)n_edges / (double)std::max(n_own, 1);
     return avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
 }
-// MODE 0: forward (owner = receiver), 1: backward receiver-ordered, 2: backward sender-ordered (owner = sender)
-template <int MODE>
-static int launch_edge(bool owner_left, const EdgeArgs& a, int n_edges, hipStream_t st) {
+// forward (owner = receiver); `save` also emits the ReLU nibbles and the N rows for the backward pass
+static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool save, hipStream_t st) {
+    if (a.n_recv <= 0) return 0;
+    if (save && (!a.cnt_rows || (n_edges > 0 && !a.mask))) return GCNN_E_BADARG;
+    const int slots = edge_slots(a.n_recv, n_edges);
+    const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
+#define EDGE_LAUNCH(S, V) hipLaunchKernelGGL((k_edge_fwd<S, V>), dim3(grid), dim3(256), 0, st, a)
+    if (save) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
+    else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
+#undef EDGE_LAUNCH
+    LAUNCHCHK();
+    return 0;
+}
+// backward, sender-ordered (owner = sender)
+static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, hipStream_t st) {
     if (a.n_recv <= 0) return 0;
     const int slots = edge_slots(a.n_recv, n_edges);
     const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
-#define EDGE_LAUNCH(K) hipLaunchKernelGGL((K), dim3(grid), dim3(256), 0, st, a)
-    if (MODE == 0) {
-        if (slots == 4) { if (owner_left) EDGE_LAUNCH((k_edge_fwd<4, true>)); else EDGE_LAUNCH((k_edge_fwd<4, false>)); }
-        else if (slots == 2) { if (owner_left) EDGE_LAUNCH((k_edge_fwd<2, true>)); else EDGE_LAUNCH((k_edge_fwd<2, false>)); }
-        else { if (owner_left) EDGE_LAUNCH((k_edge_fwd<1, true>)); else EDGE_LAUNCH((k_edge_fwd<1, false>)); }
-    } else if (MODE == 1) {
-        if (slots == 4) EDGE_LAUNCH(k_edge_bwd_recv<4>); else if (slots == 2) EDGE_LAUNCH(k_edge_bwd_recv<2>); else EDGE_LAUNCH(k_edge_bwd_recv<1>);
-    } else {
-        if (slots == 4) EDGE_LAUNCH(k_edge_bwd_send<4>); else if (slots == 2) EDGE_LAUNCH(k_edge_bwd_send<2>); else EDGE_LAUNCH(k_edge_bwd_send<1>);
-    }
-#undef EDGE_LAUNCH
+    if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
+    else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
     LAUNCHCHK();
     return 0;
 }
@@ -1024,8 +1057,9 @@ struct Acts {
 struct Work {
     Acts a, g;            // activations and their gradients
     float* partial;       // weight-gradient slabs
-    float* q[3];          // per-receiver partials of d w_edge, one [R,64] matrix per convolution
-    unsigned long long* mask[3];  // ReLU masks of the three edge passes, 64 bits per edge, receiver order
+    float* q[3];          // per-sender shares of d w_edge, one [n_send,64] matrix per convolution
+    unsigned char* mask[3];  // ReLU nibbles of the three edge passes, 16 bytes per edge, receiver order
+    float* nrow[3];          // per receiver and channel: number of active edges
     float* emb_partial[3];
     float* score_partial; int score_nblk;
     int emb_nblk[3];
@@ -1056,9 +1090,10 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     }
     w->partial = take(wg_slabs(d) * WG_SLAB);
     const size_t nrecv[3] = {C, V, K};
-    for (int i = 0; i < 3; ++i) w->q[i] = take(nrecv[i] * EMB);
+    const size_t nsend[3] = {V, C, V};
+    for (int i = 0; i < 3; ++i) { w->q[i] = take(nsend[i] * EMB); w->nrow[i] = take(nrecv[i] * EMB); }
     const size_t nedge[3] = {(size_t)d->n_cons_edges, (size_t)d->n_cons_edges, (size_t)d->n_cut_edges};
-    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned long long*)take(2 * nedge[i]);
+    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned char*)take(4 * nedge[i]);
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
@@ -1191,38 +1226,37 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
     return launch_linear(true, a, (hipStream_t)stream);
 }
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
-                       int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
-                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out,
-                       void* stream) {
+                       const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
+                       const float* e_scale, const float* s1, float* s_out, uint8_t* mask_out, float* n_rows, void* stream) {
     if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
+    const bool save = mask_out || n_rows;
     EdgeArgs e; memset(&e, 0, sizeof(e));
     e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
-    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = (unsigned long long*)mask_out; e.n_recv = n_recv;
-    return launch_edge<0>(recv_is_left != 0, e, n_edges, (hipStream_t)stream);
+    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = mask_out; e.cnt_rows = n_rows; e.n_recv = n_recv;
+    return launch_edge_fwd(e, n_edges, save, (hipStream_t)stream);
 }
-int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const float* coef, const uint64_t* mask, int32_t n_recv, int32_t n_edges,
-                            const float* e_shift, const float* e_scale, const float* s1, const float* d_s,
-                            float* d_p_recv, float* dw_rows, void* stream) {
-    if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
-    if (n_recv > 0 && (!seg_ptr || !e_shift || !e_scale || !s1 || !d_s || !d_p_recv || !dw_rows)) return GCNN_E_BADARG;
-    if (n_edges > 0 && (!coef || !mask)) return GCNN_E_BADARG;
-    EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = seg_ptr; e.coef = coef; e.mask = (unsigned long long*)mask; e.e_shift = e_shift; e.e_scale = e_scale;
-    e.s1 = s1; e.d_s = d_s; e.out = d_p_recv; e.dw_rows = dw_rows; e.n_recv = n_recv;
-    return launch_edge<1>(true, e, n_edges, (hipStream_t)stream);
+int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
+                            void* stream) {
+    if (n_recv < 0 || (n_recv > 0 && (!d_s || !n_rows || !s1 || !d_p_recv))) return GCNN_E_BADARG;
+    if (n_recv == 0) return 0;
+    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(std::min(cdiv(n_recv * 16, 256), MAX_GRID)), dim3(256), 0, (hipStream_t)stream,
+                       d_s, n_rows, s1, d_p_recv, n_recv * 16);
+    LAUNCHCHK();
+    return 0;
 }
-int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const int32_t* xpos, const uint64_t* mask,
-                            int32_t n_send, int32_t n_edges, const float* s1, const float* d_s, float* d_p_send,
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
+                            const uint8_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
                             void* stream) {
     if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
-    if (n_send > 0 && (!seg_ptr || !s1 || !d_p_send)) return GCNN_E_BADARG;
-    if (n_edges > 0 && (!oth || !xpos || !mask || !d_s)) return GCNN_E_BADARG;
+    if (n_send > 0 && (!seg_ptr || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !xpos || !mask || !d_s)) return GCNN_E_BADARG;
     EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = seg_ptr; e.oth = oth; e.xpos = xpos; e.mask = (unsigned long long*)mask; e.s1 = s1; e.d_s = d_s;
-    e.out = d_p_send; e.n_recv = n_send;
-    return launch_edge<2>(true, e, n_edges, (hipStream_t)stream);
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.xpos = xpos; e.mask = const_cast<uint8_t*>(mask); e.s1 = s1;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_recv = n_send;
+    return launch_edge_bwd_send(e, n_edges, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -1259,22 +1293,29 @@ static int launch_chain(const Chain& c, hipStream_t st) {
     const ChArgs& a = c.a;
     if (a.n <= 0 || a.nstage == 0) return 0;
     if (a.nstage > CH_MAX_STAGES || a.nw > CH_MAX_W) return GCNN_E_BADARG;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_chain<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    // every stage of a chain multiplies in the same direction; CH_EMBED1 / CH_SCORE only open / close forward chains
+    const bool transb = a.st[a.nstage - 1].type == CH_GEMM ? a.st[a.nstage - 1].transb != 0 : false;
+    for (int i = 0; i < a.nstage; ++i) {
+        if (a.st[i].type == CH_GEMM && (a.st[i].transb != 0) != transb) return GCNN_E_BADARG;
+        if (a.st[i].type == CH_EMBED1 && (i != 0 || transb)) return GCNN_E_BADARG;
+        if (a.st[i].type == CH_SCORE && (i != a.nstage - 1 || transb)) return GCNN_E_BADARG;
     }
     const int ntile = cdiv(a.n, 16);
     // one block per CU (the staged weights fill most of the LDS); 8 waves per block once there is more than one tile
     // per wave so two waves share each SIMD's MFMA pipe and hide each other's loads
-    if (ntile > 1024) {
-        const int smem = (a.nw * 64 * LDW + 8 * 2 * CH_TILE) * (int)sizeof(float);
-        hipLaunchKernelGGL(k_chain<8>, dim3(std::min(cdiv(ntile, 8), 256)), dim3(512), smem, st, a);
-    } else {
-        const int smem = (a.nw * 64 * LDW + 4 * 2 * CH_TILE) * (int)sizeof(float);
-        hipLaunchKernelGGL(k_chain<4>, dim3(std::min(cdiv(ntile, 4), 256)), dim3(256), smem, st, a);
-    }
+    const bool big = ntile > 1024;
+    const int nwaves = big ? 8 : 4;
+    const int smem = (a.nw * 64 * LDW + CH_MAX_STAGES * CH_PAR) * (int)sizeof(float);  // weights + per-stage parameters
+    const dim3 grid(std::min(cdiv(ntile, nwaves), 256)), block(nwaves * 64);
+#define CHAIN_CASE(NW, TB)                                                                                              \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_chain<NW, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+        hipLaunchKernelGGL((k_chain<NW, TB>), grid, block, smem, st, a);                                                \
+    } while (0)
+    if (big) { if (transb) CHAIN_CASE(8, true); else CHAIN_CASE(8, false); }
+    else { if (transb) CHAIN_CASE(4, true); else CHAIN_CASE(4, false); }
+#undef CHAIN_CASE
     LAUNCHCHK();
     return 0;
 }
@@ -1287,7 +1328,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
     float *PL, *PR, *S, *A, *Z1, *OUT;
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
-    unsigned long long* mask;
+    unsigned char* mask; float* N;
 };
 
 static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
@@ -1303,17 +1344,17 @@ static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
 // edge pass + the receiver-side update chain S -> A -> Z1 -> X' (model.py:498-508, 568-573); `tail` appends the stages
 // that consume X' (the next convolution's projection or the readout) to the same launch
 template <class Tail>
-static int conv_forward(const float* p, const ConvIO& c, hipStream_t st, Tail tail) {
+static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, Tail tail) {
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
-    e.out = c.S; e.mask = c.mask;
-    if ((rc = launch_edge<0>(c.recv_left, e, c.ne, st))) return rc;
+    e.out = c.S; e.mask = c.mask; e.cnt_rows = c.N;
+    if ((rc = launch_edge_fwd(e, c.ne, save, st))) return rc;
     Chain ch(nr);
-    ChStage& s0 = ch.gemm(c.S, 0, p + poff(c.pbase + C_WF), 0, c.A, 0);           // A = S Wf + deg*bf (K8 hoisted)
+    ChStage& s0 = ch.gemm(c.S, 0, p + poff(c.pbase + C_WF), 0, save ? c.A : nullptr, 0);   // A = S Wf + deg*bf (K8 hoisted)
     s0.bd = p + poff(c.pbase + C_BF); s0.seg_ptr = e.seg_ptr;
-    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 0, c.Z1, 0);      // Z1 = relu([s2*A | x_recv] W1 + b1)
+    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 0, save ? c.Z1 : nullptr, 0);   // Z1 = relu([s2*A | x_recv] W1 + b1)
     s1.sa = p + poff(c.pbase + C_S2); s1.in_b = xrecv; s1.tb = 1; s1.wb = ch.weight(p + poff(c.pbase + C_W1) + EMB * EMB);
     s1.bias = p + poff(c.pbase + C_B1); s1.relu = 1;
     ChStage& s2 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 0, c.OUT, 0);     // X' = relu(Z1 W2 + b2)
@@ -1325,11 +1366,11 @@ static int conv_forward(const float* p, const ConvIO& c, hipStream_t st, Tail ta
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.mask[0]};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.mask[0], w.nrow[0]};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.mask[1]};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.mask[1], w.nrow[1]};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.mask[2]};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.mask[2], w.nrow[2]};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -1343,25 +1384,26 @@ static int check_common(const gcnn_dims* d, const float* params, const gcnn_grap
 
 extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
-                 size_t workspace_floats, float* scores, void* stream) {
+                 size_t workspace_floats, float* scores, int32_t save_for_backward, void* stream) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
     if (d->n_cuts > 0 && !scores) return GCNN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    const bool save = save_for_backward != 0;
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
     // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496)
     {
         Chain ch(d->n_cons);  // constraints: E1 -> Xc -> PL1
-        ch.embed1(cons_feats, 4, p, P_CONS, A.E1c);
+        ch.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); s.bias = p + poff(P_CONS + E_B2); s.relu = 1;
         ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); t.bias = p + poff(P_CONV0 + C_BL);
         if ((rc = launch_chain(ch, st))) return rc;
     }
     {
         Chain ch(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
-        ch.embed1(var_feats, 14, p, P_VAR, A.E1v);
+        ch.embed1(var_feats, 14, p, P_VAR, save ? A.E1v : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 0, A.Xv, 0); s.bias = p + poff(P_VAR + E_B2); s.relu = 1;
         ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WR), 0, A.PR1, 1);
         ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WR), 0, A.PR2, 1);
@@ -1369,21 +1411,21 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     }
     {
         Chain ch(d->n_cuts);  // cuts: E1 -> Xk -> PL3
-        ch.embed1(cut_feats, 6, p, P_CUT, A.E1k);
+        ch.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); s.bias = p + poff(P_CUT + E_B2); s.relu = 1;
         ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); t.bias = p + poff(P_CONV2 + C_BL);
         if ((rc = launch_chain(ch, st))) return rc;
     }
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
-    if ((rc = conv_forward(p, cv[0], st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
+    if ((rc = conv_forward(p, cv[0], save, st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
             ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WL), 0, A.PL2, 1); t.bias = p + poff(P_CONV1 + C_BL);
         }))) return rc;
-    if ((rc = conv_forward(p, cv[1], st, [&](Chain& ch) {   // updated variables -> right projection of conv v->k
+    if ((rc = conv_forward(p, cv[1], save, st, [&](Chain& ch) {   // updated variables -> right projection of conv v->k
             ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WR), 0, A.PR3, 1);
         }))) return rc;
-    if ((rc = conv_forward(p, cv[2], st, [&](Chain& ch) {   // updated cuts -> readout (model.py:206-208, 299-300)
-            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_OUT), 0, A.O1, 0); t.bias = p + poff(P_OUT + 1); t.relu = 1;
+    if ((rc = conv_forward(p, cv[2], save, st, [&](Chain& ch) {   // updated cuts -> readout (model.py:206-208, 299-300)
+            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_OUT), 0, save ? A.O1 : nullptr, 0); t.bias = p + poff(P_OUT + 1); t.relu = 1;
             ch.score(0, p + poff(P_OUT + 2), p + poff(P_OUT + 3), scores);
         }))) return rc;
     return 0;
@@ -1425,31 +1467,33 @@ static void conv_bwd_chain(Chain& ch, const float* p, const ConvIO& c) {
     ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 1, c.gZ1, 0); s1.mask = c.Z1;
     ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1) + EMB * EMB, 1, gxrecv, 1);
     ChStage& s3 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 1, c.gA, 0); s3.so = p + poff(c.pbase + C_S2);
-    ch.gemm(nullptr, 0, p + poff(c.pbase + C_WF), 1, c.gS, 0);
+    // dS = dA Wf^T, and element-wise from it the receiver-ordered half of the edge gradient (see k_edge_fwd):
+    //   dP_recv = s1*dS*N
+    ChStage& s4 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_WF), 1, c.gS, 0);
+    s4.em_s = p + poff(c.pbase + C_S1); s4.em_a = c.N; s4.em_out = c.recv_left ? c.gPL : c.gPR;
 }
 
-// gradients of the edge pass: sender-ordered pass then receiver-ordered pass (which also emits Q, the per-receiver
-// partial of d w_edge), and the weight-gradient jobs of the whole convolution
+// sender-ordered half of the edge gradient, and the weight-gradient jobs of the whole convolution
 static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, const Work& w, JobList& jl, hipStream_t st) {
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
-    EdgeArgs e = conv_edge_args(p, c, c.recv_left);   // receiver-ordered: masks only, no row gathers
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPL : c.gPR; e.dw_rows = c.Q; e.mask = c.mask;
-    if ((rc = launch_edge<1>(c.recv_left, e, c.ne, st))) return rc;
-    e = conv_edge_args(p, c, !c.recv_left);           // sender-ordered: gathers dS rows and the 8-byte masks
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.mask = c.mask; e.xpos = c.recv_left ? c.g->v2l : c.g->l2v;
-    if ((rc = launch_edge<2>(!c.recv_left, e, c.ne, st))) return rc;
+    // the receiver-ordered half (dP_recv) came out of the chain's epilogue; sender-ordered half: dS rows + 16-B masks,
+    // which also yields Q, the per-sender share of d w_edge
+    EdgeArgs e = conv_edge_args(p, c, !c.recv_left);
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q; e.mask = c.mask; e.xpos = c.recv_left ? c.g->v2l : c.g->l2v;
+    if ((rc = launch_edge_bwd_send(e, c.ne, st))) return rc;
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
     float* gwe = grads + poff(c.pbase + C_WE);
     add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
     add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
     add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
     add_wg(jl, c.S, nullptr, c.gA, seg, nullptr, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
-    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.recv_left ? c.Q : nullptr, c.nl, grads + poff(c.pbase + C_WL),
-           grads + poff(c.pbase + C_BL), c.recv_left ? gwe : nullptr, w.partial);
-    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.recv_left ? nullptr : c.Q, c.nv, grads + poff(c.pbase + C_WR), nullptr,
-           c.recv_left ? nullptr : gwe, w.partial);
+    // Q lives on the sender side: column-summed together with the sender-side projection's job
+    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.recv_left ? nullptr : c.Q, c.nl, grads + poff(c.pbase + C_WL),
+           grads + poff(c.pbase + C_BL), c.recv_left ? nullptr : gwe, w.partial);
+    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.recv_left ? c.Q : nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr,
+           c.recv_left ? gwe : nullptr, w.partial);
     return 0;
 }
 

@@ -265,13 +265,13 @@ class GCNN:
             self._ws_pool.pop(0)
 
     # ---- forward / backward ------------------------------------------------------------------------------------
-    def _forward_into(self, flat, batch, ws):
+    def _forward_into(self, flat, batch, ws, save=True):
         scores = torch.empty(batch.dims.n_cuts, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().gcnn_forward(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
                                                _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
                                                C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(scores),
-                                               _stream(self.device)), "gcnn_forward")
+                                               int(save), _stream(self.device)), "gcnn_forward")
         return scores
 
     def _backward_into(self, flat, batch, ws, d_scores, grads):
@@ -289,7 +289,7 @@ class GCNN:
             scores = _GCNNFunction.apply(self._flat, self, batch)
         else:
             ws = self._take_workspace(batch)
-            scores = self._forward_into(self._flat.detach(), batch, ws)
+            scores = self._forward_into(self._flat.detach(), batch, ws, save=False)
             self._give_workspace(ws)
         return scores.as_subclass(ScoreTensor)
 

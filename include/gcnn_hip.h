@@ -84,33 +84,37 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
                     const float* wb, float* dx2, int32_t beta2, int32_t n, void* stream);
 
 /* ---- fused edge pass of PartialGraphConvolution.call, model.py:563-569, with Dense(feature_module_final) hoisted --
- * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * ((PL[l_e] + c_e*w_edge) + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
- *           p_recv = projected table of the receiving side [n_recv,64], p_oth = the other side's table, gathered by
- *           oth[e]; recv_is_left: receiver is the constraint/cut side (from_v=True, model.py:553-556).
- *           mask_out (optional, [E] uint64, receiver order): bit 16*k+c of word e = [s1*J_e > 0] for channel 4*c+k.
- * bwd_recv: receiver order, no row gathers: d_p_recv[r] = s1*d_s[r]*popcount_e(mask), dw_rows[r] = s1*d_s[r]*sum_e c_e*mask_e
- *           (dw_rows' column sum is the gradient of feature_module_edge's kernel, model.py:490-492).
- * bwd_send: segments grouped by the SENDING node: d_p_send[u] = s1 * sum_{e in seg(u)} mask[xpos[e]] * d_s[oth[e]];
+ * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * (PL[l_e] + c_e*w_edge + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
+ *           p_recv = projected table of the receiving side [n_recv,64] (constraint/cut side when from_v=True,
+ *           model.py:553-556), p_oth = the other side's table, gathered by oth[e].
+ *           Optional outputs for the backward pass (both or none): mask_out [E][16] bytes in receiver order, byte c of
+ *           edge e holds the bits [s1*J_e > 0] of channels 4c..4c+3; n_rows [n_recv,64] = number of active edges per
+ *           receiver and channel.
+ * bwd_recv: element-wise, because d_s[r] is constant over a segment: d_p_recv = s1*d_s*n_rows.
+ * bwd_send: segments grouped by the SENDING node; with t_e = mask[xpos[e]] * d_s[oth[e]]:
+ *           d_p_send[u] = s1*sum_{e in seg(u)} t_e ;  dw_rows[u] = s1*sum_{e in seg(u)} c_e*t_e  (its column sum is the
+ *           gradient of feature_module_edge's kernel, model.py:490-492);
  *           xpos[e] = position of edge e in the receiver-ordered list (gcnn_graph.l2v / v2l). */
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
-                       int32_t recv_is_left, const float* p_recv, const float* p_oth, const float* w_edge,
-                       const float* e_shift, const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out,
+                       const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
+                       const float* e_scale, const float* s1, float* s_out, uint8_t* mask_out, float* n_rows,
                        void* stream);
-int gcnn_conv_edge_bwd_recv(const int32_t* seg_ptr, const float* coef, const uint64_t* mask, int32_t n_recv,
-                            int32_t n_edges, const float* e_shift, const float* e_scale, const float* s1,
-                            const float* d_s, float* d_p_recv, float* dw_rows, void* stream);
-int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const int32_t* xpos, const uint64_t* mask,
-                            int32_t n_send, int32_t n_edges, const float* s1, const float* d_s, float* d_p_send,
+int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
+                            void* stream);
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
+                            const uint8_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
                             void* stream);
 
 /* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
  * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied
- * inside, model.py:365-382).  workspace: gcnn_workspace_floats(dims) floats; activations needed by
- * gcnn_backward are left there.  scores: [n_cuts] (model.py:300). */
+ * inside, model.py:365-382).  workspace: gcnn_workspace_floats(dims) floats.  save_for_backward != 0 leaves the
+ * activations, ReLU masks and edge statistics gcnn_backward needs in the workspace; 0 (inference) skips those stores.
+ * scores: [n_cuts] (model.py:300). */
 size_t gcnn_workspace_floats(const gcnn_dims* dims);
 int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
                  const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
-                 float* workspace, size_t workspace_floats, float* scores, void* stream);
+                 float* workspace, size_t workspace_floats, float* scores, int32_t save_for_backward, void* stream);
 
 /* ---- MSE head: MeanSquaredError on 1-D input, model_trainer.py:132,271 ----------------------------------------
  * loss_out[0] = scale * sum_k (scores_k - targets_k)^2 ; d_scores_k = 2*scale*(scores_k - targets_k).

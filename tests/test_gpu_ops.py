@@ -139,19 +139,21 @@ def test_conv_edge_fwd_bwd(dev, shape, recv_is_left, hub):
     g = torch.Generator().manual_seed(sum(shape) + recv_is_left)
     graph, ei, coef = _random_graph(g, n_left, n_var, n_edges, dev, hub=hub)
     pl, pr, w = _rand(g, n_left, 64), _rand(g, n_var, 64), _rand(g, 64)
-    esh, esc, s1 = torch.tensor(0.1, dtype=torch.float64), torch.tensor(1.3, dtype=torch.float64), torch.tensor(0.8, dtype=torch.float64)
+    esh, esc = torch.tensor(0.1, dtype=torch.float64), torch.tensor(1.3, dtype=torch.float64)
+    s1 = torch.tensor(-0.8 if n_edges == 1500 else 0.8, dtype=torch.float64)  # one shape exercises a negative PreNorm scale
     side = 0 if recv_is_left else 1
     n_recv = n_left if recv_is_left else n_var
     f = lambda t: t.float().reshape(-1).to(dev) if t.dim() == 0 else t.float().to(dev)
     args = (f(pl), f(pr), f(w), f(esh), f(esc), f(s1))
-    s, mask = ops.conv_edge_fwd(graph, recv_is_left, *args, want_mask=True)
+    s, saved = ops.conv_edge_fwd(graph, recv_is_left, *args, save=True)
+    _close(ops.conv_edge_fwd(graph, recv_is_left, *args), s, rtol=0, atol=0, what="inference variant")
     pl_, pr_, w_ = pl.clone().requires_grad_(), pr.clone().requires_grad_(), w.clone().requires_grad_()
     want, _, _ = _edge_reference(ei, coef, pl_, pr_, w_, esh, esc, s1, n_recv, side)
     _close(s, want, what="edge forward")
     ds = _rand(g, n_recv, 64)
     if n_edges:
         want.backward(ds)
-        d_pl, d_pr, d_w = ops.conv_edge_bwd(graph, recv_is_left, mask, f(esh), f(esc), f(s1), f(ds))
+        d_pl, d_pr, d_w = ops.conv_edge_bwd(graph, recv_is_left, saved, f(esh), f(esc), f(s1), f(ds))
         _close(d_pl, pl_.grad, rtol=1e-4, atol=1e-4, what="d PL")
         _close(d_pr, pr_.grad, rtol=1e-4, atol=1e-4, what="d PR")
         _close(d_w, w_.grad, rtol=1e-4, atol=1e-4, what="d w_edge")
