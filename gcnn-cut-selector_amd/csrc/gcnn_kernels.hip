@@ -954,6 +954,95 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// PreNorm fitting statistics (PreNormLayer.update_params, model.py:394-423): per batch, the population mean and the
+// mean squared deviation of a layer's input, per unit.  Offline path (pretraining), so: two passes (mean, then centred
+// second moment), double accumulators, per-block partials summed in a fixed order.  Three element sources:
+//   ST_COLS  a dense [n, f] matrix, one unit per column            (the five input PreNorm layers)
+//   ST_FLAT  a dense [n, 64] matrix, ONE unit over all elements     (post_conv_module, model.py:503, 570)
+//   ST_EDGE  the joint edge pre-activations J_e[64] = PL[l_e] + c_e*w + PR[v_e], ONE unit (feature_module_final's
+//            PreNorm, model.py:498, 563-565) -- never materialised
+// ---------------------------------------------------------------------------------------------------------------
+enum { ST_COLS = 0, ST_FLAT = 1, ST_EDGE = 2 };
+#define ST_MAX_UNITS 16
+#define ST_MAX_BLOCKS 1024
+struct StatArgs {
+    int src; int n; int f;                  // rows (or edges), columns/units
+    const float* x;                         // ST_COLS / ST_FLAT
+    const int* left; const int* right; const float* coef; const float* pl; const float* pr; const float* w_edge;
+    const float* e_shift; const float* e_scale;   // ST_EDGE (by-left order arrays: left id via seg search is avoided: `left` is explicit)
+    const double* mean;                     // pass 2: centre (device, [units]); nullptr in pass 1
+    double* partial;                        // [gridDim.x][units]
+};
+
+__global__ __launch_bounds__(256) void k_stats(StatArgs a) {
+    __shared__ double red[256];
+    const int units = a.src == ST_COLS ? a.f : 1;
+    double acc[ST_MAX_UNITS];
+#pragma unroll
+    for (int u = 0; u < ST_MAX_UNITS; ++u) acc[u] = 0.0;
+    if (a.src == ST_COLS) {
+        for (int r = blockIdx.x * 256 + threadIdx.x; r < a.n; r += gridDim.x * 256)
+#pragma unroll
+            for (int u = 0; u < ST_MAX_UNITS; ++u)
+                if (u < a.f) {
+                    const double v = (double)a.x[(size_t)r * a.f + u];
+                    if (a.mean) { const double d = v - a.mean[u]; acc[u] += d * d; } else acc[u] += v;
+                }
+    } else if (a.src == ST_FLAT) {
+        const double mu = a.mean ? a.mean[0] : 0.0;
+        const size_t total = (size_t)a.n * EMB;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const double v = (double)a.x[i];
+            if (a.mean) { const double d = v - mu; acc[0] += d * d; } else acc[0] += v;
+        }
+    } else {
+        const double mu = a.mean ? a.mean[0] : 0.0;
+        const float esh = *a.e_shift, esc = *a.e_scale;
+        const int ch = (threadIdx.x & 15) * 4;
+        const float4 w = *(const float4*)(a.w_edge + ch);
+        for (int e = blockIdx.x * 16 + (threadIdx.x >> 4); e < a.n; e += gridDim.x * 16) {
+            const float c = (a.coef[e] + esh) * esc;
+            const float4 p = *(const float4*)(a.pl + (size_t)a.left[e] * EMB + ch);
+            const float4 q = *(const float4*)(a.pr + (size_t)a.right[e] * EMB + ch);
+            const float jv[4] = {jointf(p.x, __fmul_rn(c, w.x), q.x), jointf(p.y, __fmul_rn(c, w.y), q.y),
+                                 jointf(p.z, __fmul_rn(c, w.z), q.z), jointf(p.w, __fmul_rn(c, w.w), q.w)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = (double)jv[k];
+                if (a.mean) { const double d = v - mu; acc[0] += d * d; } else acc[0] += v;
+            }
+        }
+    }
+    for (int u = 0; u < units; ++u) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < ST_MAX_UNITS; ++k) if (k == u) v = acc[k];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * units + u] = red[0];
+        __syncthreads();
+    }
+}
+// out[u] = (sum over blocks of partial[b][u]) / count      (one block, fixed order)
+__global__ __launch_bounds__(64) void k_stats_final(const double* __restrict__ partial, int nblocks, int units, double count,
+                                                    double* __restrict__ out) {
+    const int u = threadIdx.x;
+    if (u >= units) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * units + u];
+    out[u] = s / count;
+}
+// expand a by-left CSR pointer into explicit left ids (pretraining only)
+__global__ void k_expand_ptr(const int* __restrict__ ptr, int n_seg, int* __restrict__ ids) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_seg; r += gridDim.x * blockDim.x)
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) ids[e] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // graph plan kernels
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_iota(int* p, int n) {
@@ -1062,6 +1151,7 @@ struct Work {
     float* nrow[3];          // per receiver and channel: number of active edges
     float* emb_partial[3];
     float* score_partial; int score_nblk;
+    double* stats; int* stat_ids;   // pretraining: per-block partial sums; explicit left ids of an edge set
     int emb_nblk[3];
     size_t total;
 };
@@ -1100,6 +1190,8 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
         w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS);
         w->emb_partial[i] = take((size_t)w->emb_nblk[i] * (femb[i] + 1) * EMB);
     }
+    w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
+    w->stat_ids = (int*)take((size_t)std::max(d->n_cons_edges, d->n_cut_edges));
     w->score_nblk = cdiv(d->n_cuts, SB_ROWS);
     w->score_partial = take((size_t)w->score_nblk * 2 * EMB);
     w->total = off;
@@ -1605,6 +1697,55 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
         LAUNCHCHK();
     }
+    return 0;
+}
+
+// ---- PreNorm fitting statistics (model.py:394-423) ------------------------------------------------------------------
+extern "C" int gcnn_prenorm_stats(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                                  size_t workspace_floats, int32_t layer, double* out_mean_var, void* stream) {
+    layout_init();
+    int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
+    if (rc) return rc;
+    if (layer < 0 || layer > 10 || !out_mean_var) return GCNN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Work w; carve(d, workspace, &w);
+    StatArgs a; memset(&a, 0, sizeof(a));
+    double count = 0.0;
+    int units = 1;
+    if (layer <= 4) {   // input layers: raw features, one unit per column (edge features: a single column)
+        const float* xs[5] = {cons_feats, cg->l_coef, var_feats, cut_feats, kg->l_coef};
+        const int ns[5] = {d->n_cons, d->n_cons_edges, d->n_vars, d->n_cuts, d->n_cut_edges};
+        const int fs[5] = {4, 1, 14, 6, 1};
+        a.src = ST_COLS; a.x = xs[layer]; a.n = ns[layer]; a.f = fs[layer]; units = a.f; count = (double)a.n;
+    } else {
+        ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+        const ConvIO& c = cv[(layer - 5) >> 1];
+        if (((layer - 5) & 1) == 0) {   // feature_module_final's PreNorm: all E*64 joint pre-activations, one unit
+            a.src = ST_EDGE; a.n = c.ne; a.right = c.g->l_oth; a.coef = c.g->l_coef; a.pl = c.PL; a.pr = c.PR;
+            a.w_edge = p + poff(c.pbase + C_WE); a.e_shift = p + poff(c.pedge); a.e_scale = p + poff(c.pedge + 1);
+            if (c.ne > 0) {
+                hipLaunchKernelGGL(k_expand_ptr, dim3(std::min(cdiv(c.nl, 256), 1024)), dim3(256), 0, st, c.g->l_ptr, c.nl, w.stat_ids);
+                LAUNCHCHK();
+            }
+            a.left = w.stat_ids; count = (double)c.ne * EMB;
+        } else {                        // post_conv_module's PreNorm: all R*64 elements of the scatter-sum output, one unit
+            a.src = ST_FLAT; a.x = c.A; a.n = c.recv_left ? c.nl : c.nv; count = (double)a.n * EMB;
+        }
+    }
+    if (count <= 0.0) {   // nothing to absorb: mean 0, variance 0 (the caller skips empty batches)
+        HIPCHK(hipMemsetAsync(out_mean_var, 0, 2 * (size_t)units * sizeof(double), st));
+        return 0;
+    }
+    const int work = a.src == ST_EDGE ? cdiv(a.n, 16) : (a.src == ST_FLAT ? cdiv(a.n, 4) : cdiv(a.n, 256));
+    const int grid = std::max(1, std::min(work, ST_MAX_BLOCKS));
+    a.partial = w.stats;
+    a.mean = nullptr;
+    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, a); LAUNCHCHK();
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, st, w.stats, grid, units, count, out_mean_var); LAUNCHCHK();
+    a.mean = out_mean_var;
+    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, a); LAUNCHCHK();
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, st, w.stats, grid, units, count, out_mean_var + units); LAUNCHCHK();
     return 0;
 }
 

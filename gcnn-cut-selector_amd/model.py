@@ -53,6 +53,15 @@ VARIABLE_SPEC = (_emb_spec("cons", 4)
                     ("out_2/kernel", (EMB, 1), True), ("out_2/bias", (1,), True)])
 
 
+# The 11 PreNorm layers in CALL order (model.py:287-296, 563-570): (shift variable | None, scale variable, units).
+PRENORM_LAYERS = [("cons_prenorm/shift", "cons_prenorm/scale", 4), ("cons_edge_prenorm/shift", "cons_edge_prenorm/scale", 1),
+                  ("var_prenorm/shift", "var_prenorm/scale", 14), ("cut_prenorm/shift", "cut_prenorm/scale", 6),
+                  ("cut_edge_prenorm/shift", "cut_edge_prenorm/scale", 1),
+                  (None, "cons_conv_final_prenorm/scale", 1), (None, "cons_conv_post_prenorm/scale", 1),
+                  (None, "var_conv_final_prenorm/scale", 1), (None, "var_conv_post_prenorm/scale", 1),
+                  (None, "cut_conv_final_prenorm/scale", 1), (None, "cut_conv_post_prenorm/scale", 1)]
+
+
 class ScoreTensor(torch.Tensor):
     """Device tensor whose `.numpy()` copies to the host, so the reference's `model(...).numpy()` call sites work."""
 
@@ -295,6 +304,75 @@ class GCNN:
 
     def __call__(self, inputs, training=False):
         return self.call(inputs, training)
+
+    # ---- PreNorm pretraining hooks (model.py:69-133, 384-437) --------------------------------------------------------
+    def pretrain_init(self):
+        """BaseModel.pretrain_init (model.py:69-87): every PreNorm layer starts waiting for updates."""
+        self._prenorm_state = [dict(waiting=True, received=False, mean=np.zeros(u, np.float32), var=np.zeros(u, np.float32),
+                                    count=np.float32(0)) for _, _, u in PRENORM_LAYERS]
+
+    def pretrain(self, inputs, training=True) -> bool:
+        """BaseModel.pretrain (model.py:119-133): run the model; the first PreNorm layer (in call order) that is still
+        waiting absorbs this batch's statistics (PreNormLayer.update_params, model.py:394-423) and the call stops there
+        (the reference raises PreNormException).  Returns True when a layer absorbed the batch."""
+        if self._prenorm_state is None:
+            return False
+        waiting = [i for i, st in enumerate(self._prenorm_state) if st["waiting"]]
+        if not waiting:
+            return False
+        layer = waiting[0]
+        st = self._prenorm_state[layer]
+        units = PRENORM_LAYERS[layer][2]
+        batch = self.prepare(inputs)
+        sizes = [batch.dims.n_cons, batch.dims.n_cons_edges, batch.dims.n_vars, batch.dims.n_cuts, batch.dims.n_cut_edges]
+        if layer <= 4:
+            sample_count = sizes[layer]
+        else:
+            conv, post = (layer - 5) // 2, (layer - 5) % 2
+            n_recv = [batch.dims.n_cons, batch.dims.n_vars, batch.dims.n_cuts][conv]
+            n_edge = [batch.dims.n_cons_edges, batch.dims.n_cons_edges, batch.dims.n_cut_edges][conv]
+            sample_count = (n_recv if post else n_edge) * EMB
+        st["received"] = True
+        if sample_count == 0:
+            return True
+        ws = self._take_workspace(batch)
+        flat = self._flat.detach()
+        if layer >= 5:
+            self._forward_into(flat, batch, ws, save=True)
+        out = torch.empty(2 * units, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gcnn_prenorm_stats(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
+                                                     _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
+                                                     C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), layer, _ptr(out),
+                                                     _stream(self.device)), "gcnn_prenorm_stats")
+        host = out.cpu().numpy()
+        self._give_workspace(ws)
+        # streaming merge of Chan et al. in fp32, exactly the arithmetic of model.py:415-423
+        f = np.float32
+        sample_mean, sample_var, sample_count = host[:units].astype(f), host[units:].astype(f), f(sample_count)
+        delta = sample_mean - st["mean"]
+        m2 = st["var"] * st["count"] + sample_var * sample_count + delta ** 2 * st["count"] * sample_count / (st["count"] + sample_count)
+        st["count"] = f(st["count"] + sample_count)
+        st["mean"] = (st["mean"] + delta * sample_count / st["count"]).astype(f)
+        st["var"] = (m2 / st["count"]).astype(f)
+        return True
+
+    def pretrain_next(self):
+        """BaseModel.pretrain_next (model.py:89-117): freeze the layer that just received updates
+        (PreNormLayer.stop_updates, model.py:425-437: shift = -mean, scale = 1/sqrt(var), var == 0 -> 1)."""
+        if self._prenorm_state is None:
+            return None
+        for i, st in enumerate(self._prenorm_state):
+            if st["waiting"] and st["received"]:
+                shift_name, scale_name, units = PRENORM_LAYERS[i]
+                var = np.where(st["var"] == 0, np.float32(1), st["var"]).astype(np.float32)
+                with torch.no_grad():
+                    if shift_name is not None:
+                        self.get_variable(shift_name).copy_(torch.from_numpy((-st["mean"]).astype(np.float32)))
+                    self.get_variable(scale_name).copy_(torch.from_numpy((1 / np.sqrt(var)).astype(np.float32)))
+                st["waiting"] = False
+                return i, scale_name.rsplit("/", 1)[0]
+        return None
 
     def get_concrete_function(self):
         """Counterpart of `tf.function(model.call).get_concrete_function()` (model_evaluator.py:310-311): an inference

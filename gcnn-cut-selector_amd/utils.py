@@ -1,0 +1,64 @@
+"""Sample files and batch collation: the counterpart of the reference's `utils.load_batch` (/root/reference/utils.py:339-426)
+and of the sample format `data_collector.py` writes (data_collector.py:135-140):
+
+    gzip(pickle({'data': [(cons, cons_edge, var, cut, cut_edge), improvements]}))
+
+where cons/var/cut are {'features': [...], 'values': ndarray} and the edge dicts add 'indices' ([2,E], row 0 = left id).
+`load_batch` returns the same 11-tuple as the reference (NumPy arrays instead of tf.Tensors): stacked features, edge
+indices shifted per sample (disjoint-union batching), per-sample count vectors and the stacked improvements."""
+
+from __future__ import annotations
+
+import gzip
+import pickle
+
+import numpy as np
+
+
+def save_sample(path: str, state, improvements):
+    """Write one (state, improvements) pair in the reference's on-disk format (data_collector.py:135-140)."""
+    with gzip.open(path, "wb") as file:
+        pickle.dump({"data": [state, np.asarray(improvements)]}, file)
+
+
+def load_sample(path: str):
+    with gzip.open(path, "rb") as file:
+        sample = pickle.load(file)
+    return sample["data"]
+
+
+def collate(samples):
+    """The array half of `utils.load_batch` (utils.py:389-426) on already loaded (state, improvements) pairs."""
+    cons = [s[0][0]["values"] for s in samples]
+    var = [s[0][2]["values"] for s in samples]
+    cut = [s[0][3]["values"] for s in samples]
+    n_cons = [c.shape[0] for c in cons]
+    n_vars = [v.shape[0] for v in var]
+    n_cuts = [k.shape[0] for k in cut]
+    # cons_shift = [[0, n_cons_1, n_cons_1 + n_cons_2, ...], [0, n_var_1, ...]] (utils.py:401-407)
+    cons_shift = np.cumsum([[0] + n_cons[:-1], [0] + n_vars[:-1]], axis=1)
+    cut_shift = np.cumsum([[0] + n_cuts[:-1], [0] + n_vars[:-1]], axis=1)
+    cei = np.concatenate([s[0][1]["indices"] + cons_shift[:, j:j + 1] for j, s in enumerate(samples)], axis=1)
+    kei = np.concatenate([s[0][4]["indices"] + cut_shift[:, j:j + 1] for j, s in enumerate(samples)], axis=1)
+    f32, i32 = np.float32, np.int32
+    return (np.concatenate(cons, 0).astype(f32), cei.astype(i32),
+            np.concatenate([s[0][1]["values"] for s in samples], 0).astype(f32),
+            np.concatenate(var, 0).astype(f32), np.concatenate(cut, 0).astype(f32), kei.astype(i32),
+            np.concatenate([s[0][4]["values"] for s in samples], 0).astype(f32),
+            np.asarray(n_cons, i32), np.asarray(n_vars, i32), np.asarray(n_cuts, i32),
+            np.concatenate([np.asarray(s[1]) for s in samples]).astype(f32))
+
+
+def load_batch(sample_files):
+    """`utils.load_batch` (utils.py:339-426): gunzip + unpickle each file, then collate."""
+    return collate([load_sample(f) for f in sample_files])
+
+
+def state_to_inputs(state):
+    """A single `get_state` 5-tuple (utils.py:35-238) -> the model's 10-tuple, as the SCIP plugins build it
+    (model_evaluator.py:84-101)."""
+    cons, cons_edge, var, cut, cut_edge = state
+    f32, i32 = np.float32, np.int32
+    return (np.asarray(cons["values"], f32), np.asarray(cons_edge["indices"], i32), np.asarray(cons_edge["values"], f32),
+            np.asarray(var["values"], f32), np.asarray(cut["values"], f32), np.asarray(cut_edge["indices"], i32),
+            np.asarray(cut_edge["values"], f32), cons["values"].shape[0], var["values"].shape[0], cut["values"].shape[0])

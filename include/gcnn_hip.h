@@ -130,6 +130,16 @@ int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_
                   const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
                   float* workspace, size_t workspace_floats, const float* d_scores, float* grads, void* stream);
 
+/* ---- PreNorm fitting statistics: PreNormLayer.update_params, model.py:394-423 -----------------------------------
+ * For ONE batch and ONE of the 11 PreNorm layers (call order: 0 cons, 1 cons-edge, 2 var, 3 cut, 4 cut-edge, then
+ * 5+2k / 6+2k = feature_module_final / post_conv_module of convolution k) writes the population mean [units] followed by
+ * the mean squared deviation [units] of that layer's input to out_mean_var (device doubles; units = 4,1,14,6,1 for the
+ * input layers, 1 otherwise).  Layers >= 5 read activations of a preceding gcnn_forward(save_for_backward=1) on the same
+ * workspace, inputs and parameters.  The streaming merge over batches (Chan et al.) is the caller's, as in the reference. */
+int gcnn_prenorm_stats(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
+                       const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
+                       float* workspace, size_t workspace_floats, int32_t layer, double* out_mean_var, void* stream);
+
 /* ---- Keras-form Adam over the flat buffer: model_trainer.py:131,273 ------------------------------------------
  * theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (host double).
  * grad_scale (optional device scalar, may be NULL) multiplies every gradient first (data-parallel mean). */

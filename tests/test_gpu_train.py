@@ -1,0 +1,149 @@
+"""Training-path parity (GPU): fused train step, optimizer, reference-style process()/pretrain(), and size-independent
+properties at the BASELINE size (setcov-500 x 32)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gcnn_cut_selector_amd import synthetic, utils  # noqa: E402
+from oracle import gcnn_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def _model(seed, dev):
+    from gcnn_cut_selector_amd.model import GCNN
+    params = O.randomize_params(O.init_params(seed, np.float32), seed + 1)
+    m = GCNN(device=dev)
+    m.set_weights([params[n] for n in O.PARAM_NAMES])
+    return m, params
+
+
+def test_train_step_matches_oracle_and_autograd_path(dev):
+    from gcnn_cut_selector_amd.trainer import Adam, TrainState, train_step
+    m, params = _model(20, dev)
+    state, y, _ = synthetic.make_batch("combauc", 3)
+    batch = m.prepare(state)
+    yt = torch.as_tensor(y).to(dev)
+    ts = TrainState(m)
+    loss, scores = train_step(m, batch, yt, None, ts)
+    # the same numbers through torch autograd (the GradientTape-like path)
+    pred = m(batch, True)
+    l2 = ((pred - yt) ** 2).mean()
+    m.flat_parameters.grad = None
+    l2.backward()
+    assert torch.equal(pred.detach(), scores)
+    np.testing.assert_allclose(float(loss), float(l2.detach()), rtol=1e-6)
+    np.testing.assert_allclose(ts.grads.cpu().numpy(), m.flat_parameters.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # one optimizer step vs the oracle's Keras-form Adam on the oracle's gradients
+    _, _, grads = O.loss_and_grads({k: v.astype(np.float64) for k, v in params.items()}, state, y, torch.float64)
+    opt = Adam(learning_rate=lambda: 1e-3)
+    train_step(m, batch, yt, opt, ts)
+    for name, w in zip(O.PARAM_NAMES, m.get_weights()):
+        if name in grads:
+            want, _, _ = O.keras_adam_step(params[name].astype(np.float64), grads[name], 0 * grads[name], 0 * grads[name], 1, 1e-3)
+            # first Adam step moves every weight by ~lr*sign(g): compare the update, tolerate sign flips of ~0 gradients
+            upd, wupd = w - params[name], want - params[name]
+            big = np.abs(grads[name]) > 1e-3 * np.abs(grads[name]).max()
+            np.testing.assert_allclose(upd[big], wupd[big], rtol=2e-3, atol=2e-6, err_msg=name)
+        else:
+            np.testing.assert_array_equal(w, params[name])
+
+
+def test_data_parallel_loss_scaling_semantics(dev):
+    """train_step's DP branch back-propagates the local SUM; scaled by 1/count it must equal the single-GPU gradient."""
+    from gcnn_cut_selector_amd.trainer import TrainState, mse_loss
+    m, _ = _model(21, dev)
+    state, y, _ = synthetic.make_batch("indset", 2)
+    batch = m.prepare(state)
+    yt = torch.as_tensor(y).to(dev)
+    scores = m(batch, False)
+    _, d_mean = mse_loss(scores, yt)
+    _, d_sum = mse_loss(scores, yt, 1.0)
+    np.testing.assert_allclose((d_sum / batch.dims.n_cuts).cpu().numpy(), d_mean.cpu().numpy(), rtol=1e-6)
+
+
+def test_process_and_pretrain_mirror_reference_flow(dev, tmp_path):
+    from gcnn_cut_selector_amd.model import GCNN
+    from gcnn_cut_selector_amd.trainer import Adam, pretrain, process
+    files = []
+    for i in range(6):
+        state, imp = synthetic.make_sample("setcov", 100 + i, scale=0.1)
+        f = str(tmp_path / f"sample_{i}.pkl"); utils.save_sample(f, state, imp); files.append(f)
+    loader = [utils.load_batch(files[i:i + 2]) for i in range(0, 6, 2)]
+    m = GCNN(device=dev, seed=5)
+    assert pretrain(m, loader) == 11
+    # oracle pretraining on the same batches, same initial weights
+    p0 = dict(zip(O.PARAM_NAMES, GCNN(device=dev, seed=5).get_weights()))
+    batches = [b[:7] + (int(b[7].sum()), int(b[8].sum()), int(b[9].sum())) for b in loader]
+    fitted, _ = O.pretrain({k: v.astype(np.float64) for k, v in p0.items()}, batches, torch.float64)
+    for shift, scale, _ in O.PRENORM_LAYERS:
+        for name in (shift, scale):
+            if name:
+                np.testing.assert_allclose(m.get_variable(name).cpu().numpy(), fitted[name], rtol=1e-4, atol=1e-6, err_msg=name)
+    fractions = np.array([0.25, 0.5, 0.75, 1])
+    loss0, acc0 = process(m, loader, fractions)
+    opt = Adam(learning_rate=lambda: 1e-3)
+    for _ in range(15):
+        train_loss, _ = process(m, loader, fractions, opt)
+    loss1, acc1 = process(m, loader, fractions)
+    assert np.isfinite(loss0) and loss1 < loss0 and acc1.shape == (4,)
+    # validation loss = cut-weighted mean of per-batch MSE (model_trainer.py:304,313), checked against the oracle
+    params = dict(zip(O.PARAM_NAMES, m.get_weights()))
+    tot = cnt = 0.0
+    for b, st in zip(loader, batches):
+        pred = O.scores(params, st, torch.float32)
+        tot += float(((pred - b[10]) ** 2).sum()); cnt += len(pred)
+    np.testing.assert_allclose(loss1, tot / cnt, rtol=1e-3)
+
+
+def test_concrete_function_and_inference_mode(dev):
+    m, params = _model(22, dev)
+    state, _, _ = synthetic.make_batch("setcov", 1, scale=0.3)
+    f = m.get_concrete_function()
+    q = f(state, False).numpy()                     # the SCIP plugin's call shape (model_evaluator.py:103)
+    assert q.dtype == np.float32 and q.shape == (state[9],)
+    with torch.enable_grad():
+        t = m(state, True)                          # training-mode forward (saves activations)
+    np.testing.assert_array_equal(q, t.numpy())     # inference skips stores only: bit-identical scores
+    ranks = sorted(range(len(q)), key=lambda i: q[i], reverse=True)
+    assert len(set(ranks)) == len(q)
+
+
+# ---- BASELINE-size properties (setcov-500 x 32: ~1M edges) -----------------------------------------------------------
+def test_full_size_batching_invariance_determinism_and_finite_grads(dev):
+    from gcnn_cut_selector_amd.trainer import TrainState, train_step
+    m, _ = _model(23, dev)
+    samples = [synthetic.make_sample("setcov", i) for i in range(32)]
+    full = synthetic.stack_samples(samples)
+    state = full[:7] + (int(full[7].sum()), int(full[8].sum()), int(full[9].sum()))
+    batch = m.prepare(state)
+    a = m(batch, False).numpy()
+    assert np.array_equal(a, m(batch, False).numpy())                     # deterministic (no float atomics)
+    nk = full[9]
+    first = synthetic.stack_samples(samples[:1]); last = synthetic.stack_samples(samples[-1:])
+    s0 = m(first[:7] + (int(first[7][0]), int(first[8][0]), int(first[9][0])), False).numpy()
+    s1 = m(last[:7] + (int(last[7][0]), int(last[8][0]), int(last[9][0])), False).numpy()
+    np.testing.assert_allclose(a[:nk[0]], s0, rtol=1e-5, atol=1e-5)       # disjoint-union batching invariance
+    np.testing.assert_allclose(a[-nk[-1]:], s1, rtol=1e-5, atol=1e-5)
+    ts = TrainState(m)
+    yt = torch.as_tensor(full[10]).to(dev)
+    l1, _ = train_step(m, batch, yt, None, ts); g1 = ts.grads.clone()
+    l2, _ = train_step(m, batch, yt, None, ts)
+    assert torch.equal(g1, ts.grads) and torch.equal(l1, l2)              # bitwise reproducible gradients
+    assert bool(torch.isfinite(g1).all())
+    # linearity of the backward pass in d_scores: grads(2*d) == 2*grads(d)
+    ws = m._take_workspace(batch)
+    flat = m.flat_parameters.detach()
+    scores = m._forward_into(flat, batch, ws)
+    d = torch.randn_like(scores)
+    ga, gb = torch.empty_like(flat), torch.empty_like(flat)
+    m._backward_into(flat, batch, ws, d, ga)
+    m._forward_into(flat, batch, ws)
+    m._backward_into(flat, batch, ws, 2 * d, gb)
+    np.testing.assert_allclose(gb.cpu().numpy(), 2 * ga.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ga.abs().max()))

@@ -1,0 +1,134 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gcnn_hip.h declares (no compute calls),
+the parameter layout agrees with the oracle's checkpoint spec, sample IO / collation mirror the reference's load_batch,
+and the data-parallel host logic (sharding, flat-buffer reduction with global cut-count scaling) is exact."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from gcnn_cut_selector_amd import _lib, parallel, synthetic, utils
+from gcnn_cut_selector_amd.model import PRENORM_LAYERS, VARIABLE_SPEC
+from gcnn_cut_selector_amd.trainer import ranking_fraction
+from oracle import gcnn_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gcnn_hip.h")).read()
+    declared = set(re.findall(r"\b(gcnn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.lib()  # loads libgcnn_hip.so and binds every signature (raises if one is missing)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.gcnn_abi_version() == _lib.ABI_VERSION
+
+
+def test_parameter_layout_matches_checkpoint_spec():
+    layout, total = _lib.param_layout()
+    assert [(n, tuple(s), t) for n, s, t in VARIABLE_SPEC] == [(n, tuple(s), t) for n, s, t in O.PARAM_SPEC]
+    assert PRENORM_LAYERS == O.PRENORM_LAYERS
+    assert len(layout) == 62
+    end = 0
+    for (off, rows, cols, tr), (name, shape, trainable) in zip(layout, O.PARAM_SPEC):
+        assert off % 4 == 0 and off >= end, name          # 16-byte aligned, non-overlapping, checkpoint order
+        assert rows * cols == int(np.prod(shape)) and tr == trainable, name
+        end = off + rows * cols
+    assert total >= end and sum(r * c for _, r, c, t in layout if t) == 93121
+
+
+def test_workspace_size_query_without_gpu():
+    import ctypes as C
+    d = _lib.Dims(16000, 32000, 1893, 800000, 199704)
+    n = _lib.lib().gcnn_workspace_floats(C.byref(d))
+    assert 2 * 64 * (8 * 16000 + 9 * 32000 + 8 * 1893) <= n < 4 * 64 * (9 * 16000 + 10 * 32000 + 9 * 1893) + 64 * 1000000
+
+
+def test_product_fails_loudly_without_gpu():
+    from gcnn_cut_selector_amd.model import GCNN
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.GcnnError):
+        GCNN()
+
+
+def test_sample_roundtrip_and_load_batch(tmp_path):
+    samples = [synthetic.make_sample("combauc", i) for i in range(3)]
+    files = []
+    for i, (state, imp) in enumerate(samples):
+        f = str(tmp_path / f"sample_{i}.pkl")
+        utils.save_sample(f, state, imp)
+        files.append(f)
+    got = utils.load_batch(files)
+    want = synthetic.stack_samples(samples)
+    assert len(got) == 11
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    # edge indices are shifted per sample (utils.py:401-407): disjoint union
+    assert got[1][0].max() == got[7].sum() - 1 or got[1][0].max() < got[7].sum()
+    single = utils.state_to_inputs(samples[0][0])
+    assert single[7:] == (samples[0][0][0]["values"].shape[0], samples[0][0][2]["values"].shape[0], samples[0][0][3]["values"].shape[0])
+
+
+def test_ranking_fraction_matches_reference_semantics():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n = int(rng.integers(1, 30))
+        pred, true = rng.integers(0, 5, n).astype(float), rng.integers(0, 5, n).astype(float)  # many ties
+        assert ranking_fraction(pred, true) == O.ranking_fraction(pred, true)
+
+
+def test_shard_samples_balances_edges_and_is_deterministic():
+    sizes = [30825, 27007, 41000, 1000, 999, 35000, 28000, 30000]
+    shards = parallel.shard_samples(sizes, 4)
+    assert sorted(i for s in shards for i in s) == list(range(8))
+    loads = [sum(sizes[i] for i in s) for s in shards]
+    assert max(loads) - min(loads) <= max(sizes)
+    assert shards == parallel.shard_samples(sizes, 4)
+    assert parallel.shard_samples([5], 2) == [[0], []]
+
+
+def _dp_worker(rank, world, port, tmpdir):
+    """One data-parallel rank on CPU (gloo): local SUM-loss gradients from the oracle, ONE all-reduce of the packed buffer."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    params = O.randomize_params(O.init_params(3, np.float64), 4)
+    samples = [synthetic.make_sample("setcov", i, scale=0.05) for i in range(5)]
+    sizes = [s[0][1]["indices"].shape[1] + s[0][4]["indices"].shape[1] for s in samples]
+    mine = parallel.shard_samples(sizes, world)[rank]
+    names = [n for n, _, t in O.PARAM_SPEC if t]
+    flat = np.zeros(sum(int(np.prod(s)) for _, s, t in O.PARAM_SPEC if t))
+    n_cuts = 0
+    if mine:
+        b = synthetic.stack_samples([samples[i] for i in mine])
+        state = b[:7] + (int(b[7].sum()), int(b[8].sum()), int(b[9].sum()))
+        n_cuts = int(b[9].sum())
+        _, mean_loss, grads = O.loss_and_grads(params, state, b[10], torch.float64)
+        flat = np.concatenate([grads[n].reshape(-1) for n in names]) * n_cuts   # gradient of the local SUM
+    buf = torch.from_numpy(parallel.pack(flat, n_cuts).astype(np.float64))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    np.save(os.path.join(tmpdir, f"dp_{rank}.npy"), parallel.unpack_mean(buf.numpy()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_equals_global_batch_gradient(tmp_path):
+    """world_size 2 over gloo: the reduced, count-scaled gradient equals the gradient of the mean loss over ALL cuts of the
+    global batch (ranks hold different cut counts, so a mean of per-rank means would fail this)."""
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    params = O.randomize_params(O.init_params(3, np.float64), 4)
+    samples = [synthetic.make_sample("setcov", i, scale=0.05) for i in range(5)]
+    b = synthetic.stack_samples(samples)
+    state = b[:7] + (int(b[7].sum()), int(b[8].sum()), int(b[9].sum()))
+    _, _, grads = O.loss_and_grads(params, state, b[10], torch.float64)
+    names = [n for n, _, t in O.PARAM_SPEC if t]
+    want = np.concatenate([grads[n].reshape(-1) for n in names])
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"dp_{r}.npy"))
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * np.abs(want).max())  # the packed buffer is fp32
