@@ -75,8 +75,12 @@ def roofline_scatter_sum(batch, dev):
     ms = event_time_ms(run, 30 * nbuf, warmup=nbuf)
     nbytes = 260.0 * e + 256.0 * r  # 256+4 B per edge in, 256 B per receiver out
     achieved = nbytes / (ms * 1e-3) / 1e9
+    traffic = None  # HBM bytes per launch from the committed PMC passes (same shape only); see profiles/README.md
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath) and (e, r) == (800000, 16000):
+        traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
     return {"kernel": "k_seg_sum (scatter-sum pass, conv v->c shape)", "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_launch": nbytes, "us_per_launch": round(ms * 1e3, 2), "edges": e, "receivers": r,
             "frac_of_measured_copy_peak": round(achieved / 6290.0, 4)}
 
