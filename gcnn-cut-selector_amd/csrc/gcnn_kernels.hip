@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -667,12 +668,21 @@ struct EdgeArgs {
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
     const float* d_s;                              // send pass: dS [R,64], gathered by oth
     const int* xpos;                               // send pass: position of each edge in the receiver-ordered list
-    unsigned char* mask;                           // [E][16] ReLU nibbles in receiver order: written by forward, read by send pass
+    unsigned long long* mask;                      // [E] ReLU bits in receiver order (nibble c = channels 4c..4c+3): fwd writes, send pass reads
     float* out;                                    // S (fwd) / dP_send
     float* dw_rows;                                // send pass: Q [n_send,64], per-sender share of d w_edge
     float* cnt_rows;                               // fwd (SAVE): N[r] = number of active edges per channel
     int n_recv;
 };
+
+// OR over the 16 lanes of a DPP row (= the 16-lane group that serves one edge): rotate-and-OR by 1, 2, 4, 8
+__device__ __forceinline__ unsigned row_or16(unsigned x) {
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false);  // row_ror:1
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false);  // row_ror:2
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false);  // row_ror:4
+    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);  // row_ror:8
+    return x;
+}
 
 template <int SLOTS>
 __device__ __forceinline__ float4 slot_reduce(float4 v) {
@@ -687,8 +697,9 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
 
 // Forward edge pass.  relu(s1*J) = s1*max(J,0) for s1 >= 0 and s1*min(J,0) for s1 < 0, so the scale is applied once per
 // receiver.  J_e = (c_e*w + P_oth[oth_e]) + P_own[r].
-// SAVE also emits what the backward pass needs: per edge 16 bytes (lane c of the edge's 16-lane group stores the ReLU
-// bits of its channels 4c..4c+3 as a nibble) and per receiver/channel the number N of active edges.  Because dS[r] is
+// SAVE also emits what the backward pass needs: per edge one 64-bit word (nibble c = the ReLU bits of channels
+// 4c..4c+3, assembled across the edge's 16 lanes with DPP row rotations) and per receiver/channel the number N of
+// active edges.  Because dS[r] is
 // constant over a receiver's segment, dP_recv[r] = s1*dS[r]*N[r]: the receiver-ordered half of the backward pass is an
 // element-wise epilogue (of the chain that produces dS), not an edge pass.
 template <int SLOTS, bool SAVE, bool NEG>
@@ -713,7 +724,7 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                 if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
                 const int cnt = min(G, end - base);
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4];
+                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4]; unsigned nib[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int i = i0 + u * SLOTS + slot;
@@ -735,8 +746,18 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                             if (SAVE) {
                                 const int b0 = h0 != 0.f, b1 = h1 != 0.f, b2 = h2 != 0.f, b3 = h3 != 0.f;
                                 n0 += b0; n1 += b1; n2 += b2; n3 += b3;
-                                a.mask[(size_t)(base + i0 + u * SLOTS + slot) * 16 + cl] = (unsigned char)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3));
+                                nib[u] = (unsigned)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3));
                             }
+                        }
+                    }
+                    if (SAVE) {
+                        // each lane drops its nibble at bits 4*(c&7) of the low (c < 8) or high word; OR over the row
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const unsigned sh = nib[u] << (4 * (cl & 7));
+                            const unsigned lo = row_or16(cl < 8 ? sh : 0u), hi = row_or16(cl < 8 ? 0u : sh);
+                            if (ok[u] && cl == 0)
+                                a.mask[base + i0 + u * SLOTS + slot] = (unsigned long long)lo | ((unsigned long long)hi << 32);
                         }
                     }
                 }
@@ -770,7 +791,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_recv(const float* __restrict__
 
 // Backward, sender-ordered half: with t_e = mask_e * dS[recv(e)],
 //   dP_send[u] = s1 * sum_{e in seg(u)} t_e          Q[u] = s1 * sum_{e in seg(u)} c_e * t_e   (share of d w_edge)
-// one 256-B row gather and one 16-B mask gather (through xpos, the edge's position in the receiver-ordered list) per edge.
+// one 256-B row gather and one 8-B mask gather (through xpos, the edge's position in the receiver-ordered list) per edge.
 template <int SLOTS>
 __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
@@ -785,25 +806,29 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
             for (int base = beg; base < end; base += G) {
                 const int e = base + gl;
-                int o = 0, xp = 0; float c = 0.f;
-                if (e < end) { o = a.oth[e]; xp = a.xpos[e]; c = (a.coef[e] + esh) * esc; }
+                int o = 0; unsigned mlo = 0u, mhi = 0u; float c = 0.f;
+                if (e < end) {
+                    o = a.oth[e]; c = (a.coef[e] + esh) * esc;
+                    const unsigned long long m = a.mask[a.xpos[e]];
+                    mlo = (unsigned)m; mhi = (unsigned)(m >> 32);
+                }
                 const int cnt = min(G, end - base);
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4], xi[4]; float ci[4]; bool ok[4]; float4 d[4]; unsigned mb[4];
+                    int oi[4]; float ci[4]; bool ok[4]; float4 d[4]; unsigned mb[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int i = i0 + v * SLOTS + slot;
                         ok[v] = i < cnt;
                         const int src = gbase + (ok[v] ? i : 0);
-                        oi[v] = __shfl(o, src); xi[v] = __shfl(xp, src); ci[v] = __shfl(c, src);
+                        oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);
+                        const unsigned wlo = __shfl(mlo, src), whi = __shfl(mhi, src);  // both by every lane: a shuffle
+                        const unsigned word = cl < 8 ? wlo : whi;                        // must not sit under a lane mask
+                        mb[v] = ok[v] ? (word >> (4 * (cl & 7))) & 15u : 0u;
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        mb[v] = 0u; d[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (ok[v]) {
-                            d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
-                            mb[v] = a.mask[(size_t)xi[v] * 16 + cl];
-                        }
+                        d[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok[v]) d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -910,8 +935,8 @@ __global__ __launch_bounds__(256) void k_mse(const float* __restrict__ score, co
 }
 
 // gradient of Dense(64->1): dO1pre[k][j] = ds_k*w2[j]*[O1[k][j] > 0]; dw2[j] = sum_k ds_k O1[k][j]; db2 = sum_k ds_k.
-// One block per 256 cuts; per-block partial slab [2*64]: dw2 partial, then db2 partial in element 64.
-#define SB_ROWS 256
+// One block per SB_ROWS cuts; per-block partial slab [2*64]: dw2 partial, then db2 partial in element 64.
+#define SB_ROWS 64
 __global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_score, const float* __restrict__ o1,
                                                    const float* __restrict__ w2, float* __restrict__ d_o1,
                                                    float* __restrict__ partial, int n) {
@@ -1147,7 +1172,7 @@ struct Work {
     Acts a, g;            // activations and their gradients
     float* partial;       // weight-gradient slabs
     float* q[3];          // per-sender shares of d w_edge, one [n_send,64] matrix per convolution
-    unsigned char* mask[3];  // ReLU nibbles of the three edge passes, 16 bytes per edge, receiver order
+    unsigned long long* mask[3];  // ReLU bits of the three edge passes, 8 bytes per edge, receiver order
     float* nrow[3];          // per receiver and channel: number of active edges
     float* emb_partial[3];
     float* score_partial; int score_nblk;
@@ -1183,7 +1208,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     const size_t nsend[3] = {V, C, V};
     for (int i = 0; i < 3; ++i) { w->q[i] = take(nsend[i] * EMB); w->nrow[i] = take(nrecv[i] * EMB); }
     const size_t nedge[3] = {(size_t)d->n_cons_edges, (size_t)d->n_cons_edges, (size_t)d->n_cut_edges};
-    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned char*)take(4 * nedge[i]);
+    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned long long*)take(2 * nedge[i]);
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
@@ -1319,14 +1344,14 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
 }
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
-                       const float* e_scale, const float* s1, float* s_out, uint8_t* mask_out, float* n_rows, void* stream) {
+                       const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out, float* n_rows, void* stream) {
     if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
     const bool save = mask_out || n_rows;
     EdgeArgs e; memset(&e, 0, sizeof(e));
     e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
-    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = mask_out; e.cnt_rows = n_rows; e.n_recv = n_recv;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = (unsigned long long*)mask_out; e.cnt_rows = n_rows; e.n_recv = n_recv;
     return launch_edge_fwd(e, n_edges, save, (hipStream_t)stream);
 }
 int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
@@ -1339,14 +1364,14 @@ int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* 
     return 0;
 }
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
-                            const uint8_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+                            const uint64_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
                             const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
                             void* stream) {
     if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_send > 0 && (!seg_ptr || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !xpos || !mask || !d_s)) return GCNN_E_BADARG;
     EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.xpos = xpos; e.mask = const_cast<uint8_t*>(mask); e.s1 = s1;
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.xpos = xpos; e.mask = (unsigned long long*)mask; e.s1 = s1;
     e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_recv = n_send;
     return launch_edge_bwd_send(e, n_edges, (hipStream_t)stream);
 }
@@ -1412,6 +1437,42 @@ static int launch_chain(const Chain& c, hipStream_t st) {
     return 0;
 }
 
+// ---- side streams ---------------------------------------------------------------------------------------------
+// The step is a chain of latency-bound launches that leave most of the chip idle, so independent work runs beside it on
+// two auxiliary HIP streams, forked from / joined back into the caller's stream with events (the pattern stream capture
+// turns into parallel graph branches): the three embedding chains in the forward pass; in the backward pass the weight
+// gradient jobs of each convolution (as soon as its edge pass has finished), the cut-/constraint-row tail chains and the
+// final reduction.  Results do not depend on the interleaving (no atomics).  GCNN_STREAMS=0 runs everything in order.
+struct Side { hipStream_t s[2]; hipEvent_t ev[16]; int next; int state; };  // state: 0 = not tried, 1 = on, -1 = off
+static Side g_side = {{nullptr, nullptr}, {}, 0, 0};
+static bool side_on() {
+    if (g_side.state == 0) {
+        const char* env = getenv("GCNN_STREAMS");
+        g_side.state = -1;
+        if (!(env && env[0] == '0')) {
+            bool ok = hipStreamCreateWithFlags(&g_side.s[0], hipStreamNonBlocking) == hipSuccess &&
+                      hipStreamCreateWithFlags(&g_side.s[1], hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; ok && i < 16; ++i) ok = hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) == hipSuccess;
+            if (ok) g_side.state = 1;
+        }
+    }
+    return g_side.state == 1;
+}
+// An event record costs the recording stream ~7 us on this platform, so fork points record ONCE and let every
+// dependent stream wait on the same event.
+static int ev_record(hipStream_t on, hipEvent_t* out) {
+    hipEvent_t e = g_side.ev[g_side.next];
+    g_side.next = (g_side.next + 1) & 15;
+    HIPCHK(hipEventRecord(e, on));
+    *out = e;
+    return 0;
+}
+static int ev_wait(hipStream_t st, hipEvent_t e, hipStream_t recorded_on) {
+    if (st == recorded_on) return 0;
+    HIPCHK(hipStreamWaitEvent(st, e, 0));
+    return 0;
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------
 struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-203, 294-296)
     int pbase;            // first parameter index of the block
@@ -1420,7 +1481,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
     float *PL, *PR, *S, *A, *Z1, *OUT;
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
-    unsigned char* mask; float* N;
+    unsigned long long* mask; float* N;
 };
 
 static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
@@ -1485,13 +1546,18 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     const bool save = save_for_backward != 0;
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
-    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496)
+    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496):
+    // three independent chains -> three streams
+    const bool side = side_on();
+    hipStream_t s1 = side ? g_side.s[0] : st, s2 = side ? g_side.s[1] : st;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (side && ((rc = ev_record(st, &e0)) || (rc = ev_wait(s1, e0, st)) || (rc = ev_wait(s2, e0, st)))) return rc;
     {
         Chain ch(d->n_cons);  // constraints: E1 -> Xc -> PL1
         ch.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); s.bias = p + poff(P_CONS + E_B2); s.relu = 1;
         ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); t.bias = p + poff(P_CONV0 + C_BL);
-        if ((rc = launch_chain(ch, st))) return rc;
+        if ((rc = launch_chain(ch, s1))) return rc;
     }
     {
         Chain ch(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
@@ -1506,8 +1572,9 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
         ch.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); s.bias = p + poff(P_CUT + E_B2); s.relu = 1;
         ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); t.bias = p + poff(P_CONV2 + C_BL);
-        if ((rc = launch_chain(ch, st))) return rc;
+        if ((rc = launch_chain(ch, s2))) return rc;
     }
+    if (side && ((rc = ev_record(s1, &e1)) || (rc = ev_record(s2, &e2)) || (rc = ev_wait(st, e1, s1)) || (rc = ev_wait(st, e2, s2)))) return rc;
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     if ((rc = conv_forward(p, cv[0], save, st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
@@ -1544,6 +1611,15 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
     rd(src, gw, EMB * EMB);
     if (gb) rd(src + EMB * EMB, gb, EMB);
     if (g2) rd(src + EMB * EMB + EMB, g2, EMB);
+}
+// launch the weight-gradient jobs collected so far as one grouped kernel on `st`; slabs keep accumulating
+static int flush_wg(JobList& jl, hipStream_t st) {
+    if (jl.wg.nblocks > 0) {
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(256), 0, st, jl.wg);
+        LAUNCHCHK();
+    }
+    jl.wg.njobs = 0; jl.wg.nblocks = 0;
+    return 0;
 }
 static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int stride, int len) {
     if (nparts <= 0) return;
@@ -1624,10 +1700,28 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     const Acts &A = w.a, &G = w.g;
     JobList jl; memset(&jl, 0, sizeof(jl)); jl.wg.partial = w.partial;
 
-    // every trainable gradient is (re)written below only if its inputs are non-empty: start from zero
-    HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
+    // side streams: sw runs the weight-gradient groups and the final reduction, sc the cut-/constraint-row tail chains
+    const bool side = side_on();
+    hipStream_t sw = side ? g_side.s[0] : st, sc = side ? g_side.s[1] : st;
+    hipEvent_t ev = nullptr, ev_sc = nullptr, ev_sw = nullptr;
+    // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
+    if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
     if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
+    if ((size_t)cdiv(d->n_cons, WG_ROWS) * 8 + (size_t)cdiv(d->n_vars, WG_ROWS) * 8 + (size_t)cdiv(d->n_cuts, WG_ROWS) * 8 > wg_slabs(d))
+        return GCNN_E_WORKSPACE;
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+    struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
+        {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
+        {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
+        {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
+    // first embedding layer's weight gradient (VALU) + the reduction jobs of its slab
+    auto embed_first_layer = [&](int i, hipStream_t s) -> int {
+        int r = embed1_wgrad(em[i].f, em[i].x, p, em[i].pb, em[i].ge1, em[i].e1, w.emb_partial[i], em[i].n, w.emb_nblk[i], s);
+        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
+        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
+        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
+        return r;
+    };
 
     // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
     hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
@@ -1643,11 +1737,13 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[2], w, jl, st))) return rc;
-    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sc, ev, st)))) return rc;
+    if ((rc = flush_wg(jl, sw))) return rc;   // readout + conv v->k weight gradients
+    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k; then the cut embedding's first layer
         Chain ch(d->n_cuts);
         ChStage& s0 = ch.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); s0.add = G.Xk; s0.mask = A.Xk;
         ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
-        if ((rc = launch_chain(ch, st))) return rc;
+        if ((rc = launch_chain(ch, sc)) || (rc = embed_first_layer(2, sc))) return rc;
     }
     {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain
         Chain ch(d->n_vars);
@@ -1656,6 +1752,8 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)))) return rc;
+    if ((rc = flush_wg(jl, sw))) return rc;   // conv c->v weight gradients
     {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver chain
         Chain ch(d->n_cons);
         ChStage& s0 = ch.gemm(G.PL2, 0, p + poff(P_CONV1 + C_WL), 1, G.Xc2, 0); s0.mask = A.Xc2;
@@ -1663,6 +1761,15 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[0], w, jl, st))) return rc;
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sc, ev, st)))) return rc;
+    if ((rc = flush_wg(jl, sw))) return rc;   // conv v->c weight gradients
+    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c; then the constraint embedding's first layer
+        Chain ch(d->n_cons);
+        ChStage& s0 = ch.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); s0.add = G.Xc; s0.mask = A.Xc;
+        ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
+        if ((rc = launch_chain(ch, sc)) || (rc = embed_first_layer(0, sc))) return rc;
+        if (side && (rc = ev_record(sc, &ev_sc))) return rc;
+    }
     {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v
         Chain ch(d->n_vars);
         ChStage& s0 = ch.gemm(G.PR2, 0, p + poff(P_CONV1 + C_WR), 1, G.Xv, 0);
@@ -1670,33 +1777,18 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
         if ((rc = launch_chain(ch, st))) return rc;
     }
-    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
-        Chain ch(d->n_cons);
-        ChStage& s0 = ch.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); s0.add = G.Xc; s0.mask = A.Xc;
-        ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
-        if ((rc = launch_chain(ch, st))) return rc;
-    }
-    // embeddings: second-layer weight jobs, first-layer weight gradients on the VALU
-    struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
-        {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
-        {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
-        {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
-    for (int i = 0; i < 3; ++i) {
+    // tail on sw (needs all three tail chains): the embeddings' weight gradients, then the reduction of every slab
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sw, ev_sc, sc)))) return rc;
+    if ((rc = embed_first_layer(1, sw))) return rc;
+    for (int i = 0; i < 3; ++i)
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
-        if ((rc = embed1_wgrad(em[i].f, em[i].x, p, em[i].pb, em[i].ge1, em[i].e1, w.emb_partial[i], em[i].n, w.emb_nblk[i], st))) return rc;
-        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
-        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
-        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
-    }
+    if ((rc = flush_wg(jl, sw))) return rc;
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
-    if (jl.wg.nblocks > 0) {
-        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(256), 0, st, jl.wg);
-        LAUNCHCHK();
-    }
     if (jl.rdblk > 0) {
-        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
+        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, sw, jl.rd);
         LAUNCHCHK();
     }
+    if (side && ((rc = ev_record(sw, &ev_sw)) || (rc = ev_wait(st, ev_sw, sw)))) return rc;
     return 0;
 }
 

@@ -114,7 +114,7 @@ class _GCNNFunction(torch.autograd.Function):
         if ws is None:
             raise RuntimeError("GCNN backward called twice on the same forward pass")
         (flat,) = ctx.saved_tensors
-        grads = torch.empty_like(flat)
+        grads = torch.zeros_like(flat)  # non-trainable / padding slots are never written by gcnn_backward
         model._backward_into(flat, batch, ws, d_scores.contiguous().to(torch.float32), grads)
         model._give_workspace(ws)
         ctx.ws = None

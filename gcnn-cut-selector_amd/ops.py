@@ -55,12 +55,12 @@ def _edge_side(graph: BipartiteGraph, by_left: bool):
 
 def conv_edge_fwd(graph: BipartiteGraph, recv_is_left: bool, pl, pr, w_edge, e_shift, e_scale, s1, save=False):
     """S[r] = sum_e relu(s1*(PL[l_e] + c_e*w + PR[v_e])) over the receiver's segment (gcnn_conv_edge_fwd).
-    With save=True returns (S, saved) where saved = (mask[E,16] uint8, N[R,64]) is what conv_edge_bwd consumes."""
+    With save=True returns (S, saved) where saved = (mask[E] int64, N[R,64]) is what conv_edge_bwd consumes."""
     ptr, oth, coef, n_recv = _edge_side(graph, recv_is_left)
     p_recv, p_oth = (pl, pr) if recv_is_left else (pr, pl)
     dev = pl.device
     out = torch.empty((n_recv, EMB), dtype=torch.float32, device=dev)
-    mask = torch.empty((graph.n_edges, 16), dtype=torch.uint8, device=dev) if save else None
+    mask = torch.empty(graph.n_edges, dtype=torch.int64, device=dev) if save else None
     nrows = torch.empty((n_recv, EMB), dtype=torch.float32, device=dev) if save else None
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().gcnn_conv_edge_fwd(_ptr(ptr), _ptr(oth), _ptr(coef), n_recv, graph.n_edges, _ptr(p_recv),

@@ -87,8 +87,8 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * (PL[l_e] + c_e*w_edge + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
  *           p_recv = projected table of the receiving side [n_recv,64] (constraint/cut side when from_v=True,
  *           model.py:553-556), p_oth = the other side's table, gathered by oth[e].
- *           Optional outputs for the backward pass (both or none): mask_out [E][16] bytes in receiver order, byte c of
- *           edge e holds the bits [s1*J_e > 0] of channels 4c..4c+3; n_rows [n_recv,64] = number of active edges per
+ *           Optional outputs for the backward pass (both or none): mask_out [E] uint64 in receiver order, nibble c of
+ *           word e holds the bits [s1*J_e > 0] of channels 4c..4c+3; n_rows [n_recv,64] = number of active edges per
  *           receiver and channel.
  * bwd_recv: element-wise, because d_s[r] is constant over a segment: d_p_recv = s1*d_s*n_rows.
  * bwd_send: segments grouped by the SENDING node; with t_e = mask[xpos[e]] * d_s[oth[e]]:
@@ -97,12 +97,12 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  *           xpos[e] = position of edge e in the receiver-ordered list (gcnn_graph.l2v / v2l). */
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
-                       const float* e_scale, const float* s1, float* s_out, uint8_t* mask_out, float* n_rows,
+                       const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out, float* n_rows,
                        void* stream);
 int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
                             void* stream);
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
-                            const uint8_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+                            const uint64_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
                             const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
                             void* stream);
 
@@ -124,7 +124,7 @@ int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float sc
 
 /* ---- backward: the vector-Jacobian product tf.GradientTape computes for GCNN.call, model_trainer.py:269-272 ----
  * d_scores: [n_cuts] gradient of the loss w.r.t. the scores.  Gradients w.r.t. the 46 trainable tensors are
- * written to `grads` (flat layout; the whole buffer is zeroed first, non-trainable slots stay 0).  Must follow
+ * written to `grads` (flat layout; non-trainable and padding slots are left untouched -- keep them zero).  Must follow
  * gcnn_forward on the same workspace, inputs and parameters. */
 int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
