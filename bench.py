@@ -143,11 +143,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    import torch.distributed as dist
     group = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or os.environ.get("GCNN_FORCE_DP") == "1":  # GCNN_FORCE_DP: rehearse the collective path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
         group = dist.group.WORLD
 
     from gcnn_cut_selector_amd import synthetic
@@ -155,8 +156,7 @@ def main():
     from gcnn_cut_selector_amd.trainer import Adam, TrainState, train_step
 
     model = GCNN(device=dev, seed=0)
-    if world > 1:  # replicate rank 0's initial weights
-        import torch.distributed as dist
+    if group is not None:  # replicate rank 0's initial weights
         dist.broadcast(model.flat_parameters.detach(), src=0)
     # per-GPU work is fixed (weak scaling): rank r stacks samples [r*B, (r+1)*B)
     state, y, _ = synthetic.make_batch(args.problem, args.batch, first_sample=rank * args.batch)
@@ -170,26 +170,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        import torch.distributed as dist
+    if group is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if group is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     edges_total = float(edges_local)
-    if world > 1:
+    if group is not None:
         t = torch.tensor([elapsed, float(edges_local)], dtype=torch.float64, device=dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, edges_total = float(tmax[0]), float(t[1])
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     ms_per_step = elapsed / args.steps * 1e3
     out = {
@@ -199,7 +197,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.problem}-500 rows x batch {args.batch} per GPU (BASELINE configs[1])"
                    if args.problem == "setcov" else f"{args.problem} x batch {args.batch} per GPU",
-                   "step": "fwd + mse + bwd" + (" + rccl all-reduce(flat grads)" if world > 1 else "") + " + adam",
+                   "step": "fwd + mse + bwd" + (" + rccl all-reduce(flat grads)" if group is not None else "") + " + adam",
                    "global_batch": args.batch * world, "edges_per_step": edges_total, "n_cons": batch.dims.n_cons,
                    "n_vars": batch.dims.n_vars, "n_cuts": batch.dims.n_cuts, "parallelism": f"dp{world}",
                    "final_loss": float(loss)},
@@ -211,7 +209,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.problem, args.batch, 0)
         out["config"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch ships its own libamdhip64; loading ours first
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")
+LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
 ABI_VERSION = 1
 
 

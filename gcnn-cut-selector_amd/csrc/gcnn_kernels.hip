@@ -432,19 +432,25 @@ __global__ __launch_bounds__(NWAVES * 64) void k_chain(ChArgs a) {
     RTile pre;
     const bool have_pre = a.st[0].type == CH_GEMM && a.st[0].in_a != nullptr;
     rt_load(pre, a.st[0].in_a, tile0 * 16 + j, have_pre && tile0 * 16 + j < a.n, g);
-    // stage the chain's weights: [nw][64][LDW], a batch of loads in flight per thread
-    for (int wi = 0; wi < a.nw; ++wi) {
-        const float* __restrict__ wsrc = a.w[wi];
-        float* wdst = smem + wi * 64 * LDW;
+    // stage the chain's weights: [nw][64][LDW]; every load of every matrix is issued before the first LDS write, so the
+    // block pays ONE global round trip (up to 20 float4 per thread in flight)
+    {
         constexpr int PER = 1024 / (NWAVES * 64);  // float4 per thread per matrix: 4 (256 threads) or 2 (512)
-        float4 tmp[PER];
+        float4 tmp[CH_MAX_W][PER];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) tmp[i] = *(const float4*)(wsrc + (size_t)(i * NWAVES * 64 + threadIdx.x) * 4);
+        for (int wi = 0; wi < CH_MAX_W; ++wi)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = i * NWAVES * 64 + threadIdx.x;
-            *(float4*)(wdst + (idx >> 4) * LDW + (idx & 15) * 4) = tmp[i];
-        }
+            for (int i = 0; i < PER; ++i) {
+                tmp[wi][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wi < a.nw) tmp[wi][i] = *(const float4*)(a.w[wi] + (size_t)(i * NWAVES * 64 + threadIdx.x) * 4);
+            }
+#pragma unroll
+        for (int wi = 0; wi < CH_MAX_W; ++wi)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = i * NWAVES * 64 + threadIdx.x;
+                if (wi < a.nw) *(float4*)(smem + wi * 64 * LDW + (idx >> 4) * LDW + (idx & 15) * 4) = tmp[wi][i];
+            }
     }
     __syncthreads();
 
@@ -717,12 +723,13 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
             const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
             const float4 pown = *(const float4*)(a.p_recv + (size_t)r * EMB + ch);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+            unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;
             for (int base = beg; base < end; base += G) {
                 const int e = base + gl;
                 int o = 0; float c = 0.f;
                 if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
                 const int cnt = min(G, end - base);
+                unsigned npk = 0;   // packed byte counters: at most 16 edges per slot per chunk, no overflow
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
                     int oi[4]; float ci[4]; bool ok[4]; float4 p[4]; unsigned nib[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -744,9 +751,15 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                             h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
                             acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
                             if (SAVE) {
-                                const int b0 = h0 != 0.f, b1 = h1 != 0.f, b2 = h2 != 0.f, b3 = h3 != 0.f;
-                                n0 += b0; n1 += b1; n2 += b2; n3 += b3;
-                                nib[u] = (unsigned)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3));
+                                // active bit: h > 0 read off the float's bit pattern (+0 -> 0, anything positive -> 1)
+                                unsigned b0, b1, b2, b3;
+                                if (NEG) { b0 = h0 < 0.f; b1 = h1 < 0.f; b2 = h2 < 0.f; b3 = h3 < 0.f; }
+                                else {
+                                    b0 = (__float_as_uint(h0) + 0x7fffffffu) >> 31; b1 = (__float_as_uint(h1) + 0x7fffffffu) >> 31;
+                                    b2 = (__float_as_uint(h2) + 0x7fffffffu) >> 31; b3 = (__float_as_uint(h3) + 0x7fffffffu) >> 31;
+                                }
+                                nib[u] = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3);
+                                npk += (nib[u] * 0x00204081u) & 0x01010101u;   // four 8-bit counters, one per channel
                             }
                         }
                     }
@@ -761,6 +774,7 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                         }
                     }
                 }
+                if (SAVE) { n0 += npk & 255u; n1 += (npk >> 8) & 255u; n2 += (npk >> 16) & 255u; n3 += npk >> 24; }
             }
             acc = slot_reduce<SLOTS>(acc);
             if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
