@@ -1,0 +1,775 @@
+// gcnn_capi.hip -- C ABI (include/gcnn_hip.h) and host-side orchestration of the gfx950 (MI355X / CDNA4) kernels for the
+// bipartite GCNN hot path.  Kernels: k_chain.hpp (fused row chains), k_edge.hpp (edge passes, scatter-sum), k_wgrad.hpp
+// (weight gradients), k_linear.hpp (standalone GEMM), k_misc.hpp (heads, Adam, PreNorm statistics, graph plan).
+//
+// Reference semantics (all cites into /root/reference): GCNN.call model.py:257-300, PartialGraphConvolution.call
+// model.py:533-575, PreNormLayer.call model.py:365-382, loss/step model_trainer.py:266-273.
+//
+// Design: every node tensor is a row-major [N,64] fp32 matrix (256-B rows).  The per-edge
+// Dense(64->64) of the reference (model.py:499-500) is hoisted past the scatter-sum
+//   sum_e (H_e W_f + b_f) = (sum_e H_e) W_f + deg_r b_f
+// so the edge pass only gathers rows, applies ReLU and accumulates in registers (atomic-free segmented sum over
+// receiver-sorted CSR); all 64x64 products run on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with weights staged in LDS.
+// Wavefront = 64 lanes everywhere.  No atomics on floats anywhere: every sum has a fixed order => bitwise
+// reproducible results.
+
+#include "gcnn_common.hpp"
+#include "k_chain.hpp"
+#include "k_edge.hpp"
+#include "k_linear.hpp"
+#include "k_misc.hpp"
+#include "k_wgrad.hpp"
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static const int LIN_SMEM = (2 * 64 * LDW + 4 * 32 * LDW) * (int)sizeof(float);  // 69,632 B
+static const int MAX_GRID = 2048;
+
+static int launch_linear(bool transb, const LinArgs& a, hipStream_t st) {
+    if (a.n <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {  // 68 KB of dynamic LDS per block (gfx950 has 160 KB per CU)
+        HIPCHK(hipFuncSetAttribute((const void*)k_linear<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM));
+        HIPCHK(hipFuncSetAttribute((const void*)k_linear<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM));
+        attr_set = true;
+    }
+    const int grid = std::min(cdiv(a.n, 128), MAX_GRID);
+    if (transb) hipLaunchKernelGGL(k_linear<true>, dim3(grid), dim3(256), LIN_SMEM, st, a);
+    else hipLaunchKernelGGL(k_linear<false>, dim3(grid), dim3(256), LIN_SMEM, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+
+static LinArgs lin_fwd(const float* xa, const float* wa, const float* bias, int relu, float* y, int n) {
+    LinArgs a; memset(&a, 0, sizeof(a));
+    a.xa = xa; a.wa = wa; a.bias = bias; a.relu = relu; a.y = y; a.n = n;
+    return a;
+}
+static LinArgs lin_bwd(const float* dy, const float* ymask, const float* wa, float* dx, int beta, int n) {
+    LinArgs a; memset(&a, 0, sizeof(a));
+    a.xa = dy; a.ymask = ymask; a.write_back = ymask != nullptr; a.wa = wa; a.y = dx; a.beta_y = beta; a.n = n;
+    return a;
+}
+
+static inline int edge_slots(int n_own, int n_edges) {
+    const double avg = (double)n_edges / (double)std::max(n_own, 1);
+    return avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
+}
+// forward (owner = receiver); `save` also emits the ReLU nibbles and the N rows for the backward pass
+static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool save, hipStream_t st) {
+    if (a.n_recv <= 0) return 0;
+    if (save && (!a.cnt_rows || (n_edges > 0 && !a.mask))) return GCNN_E_BADARG;
+    const int slots = edge_slots(a.n_recv, n_edges);
+    const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
+#define EDGE_LAUNCH(S, V) hipLaunchKernelGGL((k_edge_fwd<S, V>), dim3(grid), dim3(256), 0, st, a)
+    if (save) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
+    else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
+#undef EDGE_LAUNCH
+    LAUNCHCHK();
+    return 0;
+}
+// backward, sender-ordered (owner = sender)
+static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, hipStream_t st) {
+    if (a.n_recv <= 0) return 0;
+    const int slots = edge_slots(a.n_recv, n_edges);
+    const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
+    if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
+    else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---- workspace carving ------------------------------------------------------------------------------------------
+struct Acts {
+    float *E1c, *Xc, *PL1, *S1, *A1, *Z1c, *Xc2, *PL2;          // C rows
+    float *E1v, *Xv, *PR1, *PR2, *S2, *A2, *Z1v, *Xv2, *PR3;    // V rows
+    float *E1k, *Xk, *PL3, *S3, *A3, *Z1k, *Xk2, *O1;           // K rows
+};
+struct Work {
+    Acts a, g;            // activations and their gradients
+    float* partial;       // weight-gradient slabs
+    float* q[3];          // per-sender shares of d w_edge, one [n_send,64] matrix per convolution
+    unsigned long long* mask[3];  // ReLU bits of the three edge passes, 8 bytes per edge, receiver order
+    float* nrow[3];          // per receiver and channel: number of active edges
+    float* emb_partial[3];
+    float* score_partial; int score_nblk;
+    double* stats; int* stat_ids;   // pretraining: per-block partial sums; explicit left ids of an edge set
+    int emb_nblk[3];
+    size_t total;
+};
+static inline size_t al4(size_t x) { return (x + 3) & ~(size_t)3; }
+#define EMB1_ROWS 128
+
+static size_t wg_slabs(const gcnn_dims* d) {  // total number of wgrad slabs over all 22 jobs
+    const int C = d->n_cons, V = d->n_vars, K = d->n_cuts;
+    const int bc = cdiv(C, WG_ROWS), bv = cdiv(V, WG_ROWS), bk = cdiv(K, WG_ROWS);
+    // jobs per row set (see gcnn_backward): cons 7, var 8, cut 7; 8 each leaves slack
+    return (size_t)bc * 8 + (size_t)bv * 8 + (size_t)bk * 8;
+}
+
+static void carve(const gcnn_dims* d, float* base, Work* w) {
+    const size_t C = d->n_cons, V = d->n_vars, K = d->n_cuts;
+    size_t off = 0;
+    auto take = [&](size_t n) { float* p = base ? base + off : nullptr; off += al4(n); return p; };
+    for (int pass = 0; pass < 2; ++pass) {
+        Acts* t = pass ? &w->g : &w->a;
+        float** pc[] = {&t->E1c, &t->Xc, &t->PL1, &t->S1, &t->A1, &t->Z1c, &t->Xc2, &t->PL2};
+        float** pv[] = {&t->E1v, &t->Xv, &t->PR1, &t->PR2, &t->S2, &t->A2, &t->Z1v, &t->Xv2, &t->PR3};
+        float** pk[] = {&t->E1k, &t->Xk, &t->PL3, &t->S3, &t->A3, &t->Z1k, &t->Xk2, &t->O1};
+        for (auto p : pc) *p = take(C * EMB);
+        for (auto p : pv) *p = take(V * EMB);
+        for (auto p : pk) *p = take(K * EMB);
+    }
+    w->partial = take(wg_slabs(d) * WG_SLAB);
+    const size_t nrecv[3] = {C, V, K};
+    const size_t nsend[3] = {V, C, V};
+    for (int i = 0; i < 3; ++i) { w->q[i] = take(nsend[i] * EMB); w->nrow[i] = take(nrecv[i] * EMB); }
+    const size_t nedge[3] = {(size_t)d->n_cons_edges, (size_t)d->n_cons_edges, (size_t)d->n_cut_edges};
+    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned long long*)take(2 * nedge[i]);
+    const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
+    const int femb[3] = {4, 14, 6};
+    for (int i = 0; i < 3; ++i) {
+        w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS);
+        w->emb_partial[i] = take((size_t)w->emb_nblk[i] * (femb[i] + 1) * EMB);
+    }
+    w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
+    w->stat_ids = (int*)take((size_t)std::max(d->n_cons_edges, d->n_cut_edges));
+    w->score_nblk = cdiv(d->n_cuts, SB_ROWS);
+    w->score_partial = take((size_t)w->score_nblk * 2 * EMB);
+    w->total = off;
+}
+
+extern "C" {
+
+int gcnn_abi_version(void) { return 1; }
+int gcnn_param_count(void) { return GCNN_N_PARAMS; }
+int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
+int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
+    layout_init();
+    if (index < 0 || index >= GCNN_N_PARAMS) return GCNN_E_BADARG;
+    if (offset) *offset = g_pinfo[index].off;
+    if (rows) *rows = g_pinfo[index].rows;
+    if (cols) *cols = g_pinfo[index].cols;
+    if (trainable) *trainable = g_pinfo[index].trainable;
+    return 0;
+}
+
+size_t gcnn_workspace_floats(const gcnn_dims* dims) {
+    if (!dims) return 0;
+    Work w; carve(dims, nullptr, &w);
+    return w.total;
+}
+
+// ---- graph plan -------------------------------------------------------------------------------------------------
+static size_t sort_temp_bytes(int n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr,
+                                       (int*)nullptr, n > 0 ? n : 1);
+    return (bytes + 255) & ~(size_t)255;
+}
+size_t gcnn_graph_temp_bytes(int32_t n_edges) {
+    const size_t e = ((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int) + 255) & ~(size_t)255;
+    return sort_temp_bytes(n_edges) + 5 * e;  // cub temp + iota + sorted keys + two permutations + one inverse
+}
+
+int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left, int32_t n_var,
+                     int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth, float* v_coef,
+                     int32_t* l2v, int32_t* v2l, int32_t* l_perm, void* temp, size_t temp_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_edges < 0 || n_left < 0 || n_var < 0 || !l_ptr || !v_ptr) return GCNN_E_BADARG;
+    if (temp_bytes < gcnn_graph_temp_bytes(n_edges)) return GCNN_E_WORKSPACE;
+    if (n_edges == 0) {
+        HIPCHK(hipMemsetAsync(l_ptr, 0, (size_t)(n_left + 1) * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(v_ptr, 0, (size_t)(n_var + 1) * sizeof(int), st));
+        return 0;
+    }
+    if (!edge_inds || !edge_feats || !l_oth || !l_coef || !v_oth || !v_coef || !temp) return GCNN_E_BADARG;
+    const size_t e = ((size_t)n_edges * sizeof(int) + 255) & ~(size_t)255;
+    size_t cub_bytes = sort_temp_bytes(n_edges);
+    char* t = (char*)temp;
+    void* cub_tmp = t;
+    int* iota = (int*)(t + cub_bytes);
+    int* keys = (int*)(t + cub_bytes + e);
+    int* perm[2] = {(int*)(t + cub_bytes + 2 * e), (int*)(t + cub_bytes + 3 * e)};
+    int* inv = (int*)(t + cub_bytes + 4 * e);
+    const int grid = std::min(cdiv(n_edges + 1, 256), 4096);
+    const int* left = edge_inds;
+    const int* var = edge_inds + n_edges;
+    hipLaunchKernelGGL(k_iota, dim3(grid), dim3(256), 0, st, iota, n_edges);
+    LAUNCHCHK();
+    for (int side = 0; side < 2; ++side) {
+        const int* key_in = side == 0 ? left : var;
+        const int nseg = side == 0 ? n_left : n_var;
+        int bits = 1;
+        while ((1ll << bits) < (long long)nseg + 1 && bits < 31) ++bits;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, keys, (const int*)iota, perm[side], n_edges,
+                                                  0, bits, st));
+        hipLaunchKernelGGL(k_seg_offsets, dim3(grid), dim3(256), 0, st, keys, n_edges, nseg, side == 0 ? l_ptr : v_ptr);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_gather_edges, dim3(grid), dim3(256), 0, st, perm[side], side == 0 ? var : left, edge_feats,
+                           n_edges, side == 0 ? l_oth : v_oth, side == 0 ? l_coef : v_coef);
+        LAUNCHCHK();
+    }
+    if (l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm[0], (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (v2l) {  // by-variable position -> by-left position of the same edge
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[0], n_edges, inv); LAUNCHCHK();
+        hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[1], inv, n_edges, v2l); LAUNCHCHK();
+    }
+    if (l2v) {
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[1], n_edges, inv); LAUNCHCHK();
+        hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[0], inv, n_edges, l2v); LAUNCHCHK();
+    }
+    return 0;
+}
+
+// ---- standalone scatter-sum pass --------------------------------------------------------------------------------
+int gcnn_seg_sum_f32(const float* msg, const int32_t* seg_ptr, const int32_t* perm, int32_t n_recv, float* out,
+                     void* stream) {
+    if (n_recv < 0 || (n_recv > 0 && (!seg_ptr || !out))) return GCNN_E_BADARG;  // msg may be NULL when E == 0
+    if (n_recv == 0) return 0;
+    const int grid = std::min(cdiv(n_recv, 4), 8192);
+    if (perm) hipLaunchKernelGGL((k_seg_sum<4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, seg_ptr, perm, n_recv, out);
+    else hipLaunchKernelGGL((k_seg_sum<4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, msg, seg_ptr, perm, n_recv, out);
+    LAUNCHCHK();
+    return 0;
+}
+int gcnn_seg_bcast_f32(const float* d_out, const int32_t* seg_ptr, const int32_t* perm, int32_t n_recv, float* d_msg,
+                       void* stream) {
+    if (n_recv < 0 || (n_recv > 0 && (!d_out || !seg_ptr))) return GCNN_E_BADARG;  // d_msg may be NULL when E == 0
+    if (n_recv == 0) return 0;
+    const int grid = std::min(cdiv(n_recv, 4), 8192);
+    if (perm) hipLaunchKernelGGL((k_seg_bcast<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, d_out, seg_ptr, perm, n_recv, d_msg);
+    else hipLaunchKernelGGL((k_seg_bcast<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, d_out, seg_ptr, perm, n_recv, d_msg);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---- per-op entry points (also the unit-test surface) -------------------------------------------------------------
+int gcnn_linear_fwd(const float* xa, const float* sa, const float* wa, const float* xb, const float* wb, const float* bias,
+                    const float* bd, const int32_t* seg_ptr, int32_t relu, float* y, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!xa || !wa || !y)) || (xb && !wb) || (bd && !seg_ptr)) return GCNN_E_BADARG;
+    LinArgs a = lin_fwd(xa, wa, bias, relu, y, n);
+    a.sa = sa; a.xb = xb; a.wb = xb ? wb : nullptr; a.bd = bd; a.seg_ptr = seg_ptr;
+    return launch_linear(false, a, (hipStream_t)stream);
+}
+int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float* so, float* dx, int32_t beta,
+                    const float* wb, float* dx2, int32_t beta2, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && (!dy || !wa || !dx)) || (dx2 && !wb)) return GCNN_E_BADARG;
+    LinArgs a = lin_bwd(dy, ymask, wa, dx, beta, n);
+    a.so = so; a.wb = dx2 ? wb : nullptr; a.y2 = dx2; a.beta_y2 = beta2;
+    return launch_linear(true, a, (hipStream_t)stream);
+}
+int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
+                       const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
+                       const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out, float* n_rows, void* stream) {
+    if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
+    if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
+    const bool save = mask_out || n_rows;
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = (unsigned long long*)mask_out; e.cnt_rows = n_rows; e.n_recv = n_recv;
+    return launch_edge_fwd(e, n_edges, save, (hipStream_t)stream);
+}
+int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
+                            void* stream) {
+    if (n_recv < 0 || (n_recv > 0 && (!d_s || !n_rows || !s1 || !d_p_recv))) return GCNN_E_BADARG;
+    if (n_recv == 0) return 0;
+    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(std::min(cdiv(n_recv * 16, 256), MAX_GRID)), dim3(256), 0, (hipStream_t)stream,
+                       d_s, n_rows, s1, d_p_recv, n_recv * 16);
+    LAUNCHCHK();
+    return 0;
+}
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
+                            const uint64_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
+                            void* stream) {
+    if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
+    if (n_send > 0 && (!seg_ptr || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !xpos || !mask || !d_s)) return GCNN_E_BADARG;
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.xpos = xpos; e.mask = (unsigned long long*)mask; e.s1 = s1;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_recv = n_send;
+    return launch_edge_bwd_send(e, n_edges, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- fused row chains: host-side builders --------------------------------------------------------------------------
+struct Chain {
+    ChArgs a;
+    Chain(int n) { memset(&a, 0, sizeof(a)); a.n = n; }
+    int weight(const float* w) {  // returns the LDS slot of a 64x64 weight, staging each distinct matrix once
+        for (int i = 0; i < a.nw; ++i)
+            if (a.w[i] == w) return i;
+        a.w[a.nw] = w;
+        return a.nw++;
+    }
+    ChStage& gemm(const float* in_a, int ta, const float* w, int transb, float* out, int tout) {
+        ChStage& s = a.st[a.nstage++];
+        s.type = CH_GEMM; s.in_a = in_a; s.ta = ta; s.wa = weight(w); s.transb = transb; s.out = out; s.tout = tout;
+        return s;
+    }
+    ChStage& embed1(const float* x, int f, const float* p, int pb, float* out) {
+        ChStage& s = a.st[a.nstage++];
+        s.type = CH_EMBED1; s.x_raw = x; s.nfeat = f; s.shift = p + poff(pb + E_SHIFT); s.scale = p + poff(pb + E_SCALE);
+        s.w1 = p + poff(pb + E_W1); s.bias = p + poff(pb + E_B1); s.relu = 1; s.out = out; s.tout = 0;
+        return s;
+    }
+    ChStage& score(int ta, const float* w, const float* b, float* out) {
+        ChStage& s = a.st[a.nstage++];
+        s.type = CH_SCORE; s.ta = ta; s.w1 = w; s.bias = b; s.out = out;
+        return s;
+    }
+};
+
+static int launch_chain(const Chain& c, hipStream_t st) {
+    const ChArgs& a = c.a;
+    if (a.n <= 0 || a.nstage == 0) return 0;
+    if (a.nstage > CH_MAX_STAGES || a.nw > CH_MAX_W) return GCNN_E_BADARG;
+    // every stage of a chain multiplies in the same direction; CH_EMBED1 / CH_SCORE only open / close forward chains
+    const bool transb = a.st[a.nstage - 1].type == CH_GEMM ? a.st[a.nstage - 1].transb != 0 : false;
+    for (int i = 0; i < a.nstage; ++i) {
+        if (a.st[i].type == CH_GEMM && (a.st[i].transb != 0) != transb) return GCNN_E_BADARG;
+        if (a.st[i].type == CH_EMBED1 && (i != 0 || transb)) return GCNN_E_BADARG;
+        if (a.st[i].type == CH_SCORE && (i != a.nstage - 1 || transb)) return GCNN_E_BADARG;
+    }
+    const int ntile = cdiv(a.n, 16);
+    // one block per CU (the staged weights fill most of the LDS); 8 waves per block once there is more than one tile
+    // per wave so two waves share each SIMD's MFMA pipe and hide each other's loads
+    const bool big = ntile > 1024;
+    const int nwaves = big ? 8 : 4;
+    const int smem = (a.nw * 64 * LDW + CH_MAX_STAGES * CH_PAR) * (int)sizeof(float);  // weights + per-stage parameters
+    const dim3 grid(std::min(cdiv(ntile, nwaves), 256)), block(nwaves * 64);
+#define CHAIN_CASE(NW, TB)                                                                                              \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_chain<NW, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
+        hipLaunchKernelGGL((k_chain<NW, TB>), grid, block, smem, st, a);                                                \
+    } while (0)
+    if (big) { if (transb) CHAIN_CASE(8, true); else CHAIN_CASE(8, false); }
+    else { if (transb) CHAIN_CASE(4, true); else CHAIN_CASE(4, false); }
+#undef CHAIN_CASE
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---- side streams ---------------------------------------------------------------------------------------------
+// The step is a chain of latency-bound launches that leave most of the chip idle, so independent work runs beside it on
+// two auxiliary HIP streams, forked from / joined back into the caller's stream with events (the pattern stream capture
+// turns into parallel graph branches): the three embedding chains in the forward pass; in the backward pass the weight
+// gradient jobs of each convolution (as soon as its edge pass has finished), the cut-/constraint-row tail chains and the
+// final reduction.  Results do not depend on the interleaving (no atomics).  GCNN_STREAMS=0 runs everything in order.
+struct Side { hipStream_t s[2]; hipEvent_t ev[16]; int next; int state; };  // state: 0 = not tried, 1 = on, -1 = off
+static Side g_side = {{nullptr, nullptr}, {}, 0, 0};
+static bool side_on() {
+    if (g_side.state == 0) {
+        const char* env = getenv("GCNN_STREAMS");
+        g_side.state = -1;
+        if (!(env && env[0] == '0')) {
+            bool ok = hipStreamCreateWithFlags(&g_side.s[0], hipStreamNonBlocking) == hipSuccess &&
+                      hipStreamCreateWithFlags(&g_side.s[1], hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; ok && i < 16; ++i) ok = hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) == hipSuccess;
+            if (ok) g_side.state = 1;
+        }
+    }
+    return g_side.state == 1;
+}
+// An event record costs the recording stream ~7 us on this platform, so fork points record ONCE and let every
+// dependent stream wait on the same event.
+static int ev_record(hipStream_t on, hipEvent_t* out) {
+    hipEvent_t e = g_side.ev[g_side.next];
+    g_side.next = (g_side.next + 1) & 15;
+    HIPCHK(hipEventRecord(e, on));
+    *out = e;
+    return 0;
+}
+static int ev_wait(hipStream_t st, hipEvent_t e, hipStream_t recorded_on) {
+    if (st == recorded_on) return 0;
+    HIPCHK(hipStreamWaitEvent(st, e, 0));
+    return 0;
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-203, 294-296)
+    int pbase;            // first parameter index of the block
+    const float* xl; const float* xv; int nl, nv, ne;
+    bool recv_left;
+    const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
+    float *PL, *PR, *S, *A, *Z1, *OUT;
+    float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
+    unsigned long long* mask; float* N;
+};
+
+static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
+    EdgeArgs e; memset(&e, 0, sizeof(e));
+    e.seg_ptr = by_left ? c.g->l_ptr : c.g->v_ptr; e.oth = by_left ? c.g->l_oth : c.g->v_oth;
+    e.coef = by_left ? c.g->l_coef : c.g->v_coef;
+    e.p_recv = by_left ? c.PL : c.PR; e.p_oth = by_left ? c.PR : c.PL;   // segment owner's table / gathered table
+    e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
+    e.s1 = p + poff(c.pbase + C_S1); e.n_recv = by_left ? c.nl : c.nv;
+    return e;
+}
+
+// edge pass + the receiver-side update chain S -> A -> Z1 -> X' (model.py:498-508, 568-573); `tail` appends the stages
+// that consume X' (the next convolution's projection or the readout) to the same launch
+template <class Tail>
+static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, Tail tail) {
+    int rc;
+    const int nr = c.recv_left ? c.nl : c.nv;
+    const float* xrecv = c.recv_left ? c.xl : c.xv;
+    EdgeArgs e = conv_edge_args(p, c, c.recv_left);
+    e.out = c.S; e.mask = c.mask; e.cnt_rows = c.N;
+    if ((rc = launch_edge_fwd(e, c.ne, save, st))) return rc;
+    Chain ch(nr);
+    ChStage& s0 = ch.gemm(c.S, 0, p + poff(c.pbase + C_WF), 0, save ? c.A : nullptr, 0);   // A = S Wf + deg*bf (K8 hoisted)
+    s0.bd = p + poff(c.pbase + C_BF); s0.seg_ptr = e.seg_ptr;
+    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 0, save ? c.Z1 : nullptr, 0);   // Z1 = relu([s2*A | x_recv] W1 + b1)
+    s1.sa = p + poff(c.pbase + C_S2); s1.in_b = xrecv; s1.tb = 1; s1.wb = ch.weight(p + poff(c.pbase + C_W1) + EMB * EMB);
+    s1.bias = p + poff(c.pbase + C_B1); s1.relu = 1;
+    ChStage& s2 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 0, c.OUT, 0);     // X' = relu(Z1 W2 + b2)
+    s2.bias = p + poff(c.pbase + C_B2); s2.relu = 1;
+    tail(ch);
+    return launch_chain(ch, st);
+}
+
+static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
+    const Acts &A = w.a, &G = w.g;
+    cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.mask[0], w.nrow[0]};
+    cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.mask[1], w.nrow[1]};
+    cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.mask[2], w.nrow[2]};
+}
+
+static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
+                        float* workspace, size_t workspace_floats) {
+    if (!d || !params || !cg || !kg) return GCNN_E_BADARG;
+    if (d->n_cons < 0 || d->n_vars < 0 || d->n_cuts < 0 || d->n_cons_edges < 0 || d->n_cut_edges < 0) return GCNN_E_BADARG;
+    if (!workspace || workspace_floats < gcnn_workspace_floats(d)) return GCNN_E_WORKSPACE;
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)params & 15)) return GCNN_E_BADARG;
+    return 0;
+}
+
+extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                 const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                 size_t workspace_floats, float* scores, int32_t save_for_backward, void* stream) {
+    layout_init();
+    int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
+    if (rc) return rc;
+    if (d->n_cuts > 0 && !scores) return GCNN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool save = save_for_backward != 0;
+    Work w; carve(d, workspace, &w);
+    const Acts& A = w.a;
+    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496):
+    // three independent chains -> three streams
+    const bool side = side_on();
+    hipStream_t s1 = side ? g_side.s[0] : st, s2 = side ? g_side.s[1] : st;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (side && ((rc = ev_record(st, &e0)) || (rc = ev_wait(s1, e0, st)) || (rc = ev_wait(s2, e0, st)))) return rc;
+    {
+        Chain ch(d->n_cons);  // constraints: E1 -> Xc -> PL1
+        ch.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
+        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); s.bias = p + poff(P_CONS + E_B2); s.relu = 1;
+        ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); t.bias = p + poff(P_CONV0 + C_BL);
+        if ((rc = launch_chain(ch, s1))) return rc;
+    }
+    {
+        Chain ch(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
+        ch.embed1(var_feats, 14, p, P_VAR, save ? A.E1v : nullptr);
+        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 0, A.Xv, 0); s.bias = p + poff(P_VAR + E_B2); s.relu = 1;
+        ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WR), 0, A.PR1, 1);
+        ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WR), 0, A.PR2, 1);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    {
+        Chain ch(d->n_cuts);  // cuts: E1 -> Xk -> PL3
+        ch.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
+        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); s.bias = p + poff(P_CUT + E_B2); s.relu = 1;
+        ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); t.bias = p + poff(P_CONV2 + C_BL);
+        if ((rc = launch_chain(ch, s2))) return rc;
+    }
+    if (side && ((rc = ev_record(s1, &e1)) || (rc = ev_record(s2, &e2)) || (rc = ev_wait(st, e1, s1)) || (rc = ev_wait(st, e2, s2)))) return rc;
+    // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
+    ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+    if ((rc = conv_forward(p, cv[0], save, st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
+            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WL), 0, A.PL2, 1); t.bias = p + poff(P_CONV1 + C_BL);
+        }))) return rc;
+    if ((rc = conv_forward(p, cv[1], save, st, [&](Chain& ch) {   // updated variables -> right projection of conv v->k
+            ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WR), 0, A.PR3, 1);
+        }))) return rc;
+    if ((rc = conv_forward(p, cv[2], save, st, [&](Chain& ch) {   // updated cuts -> readout (model.py:206-208, 299-300)
+            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_OUT), 0, save ? A.O1 : nullptr, 0); t.bias = p + poff(P_OUT + 1); t.relu = 1;
+            ch.score(0, p + poff(P_OUT + 2), p + poff(P_OUT + 3), scores);
+        }))) return rc;
+    return 0;
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+struct JobList {
+    WgArgs wg; RdArgs rd; int nslab;
+    int rdblk;
+};
+static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr, const float* d2,
+                   int n, float* gw, float* gb, float* g2, float* partial) {
+    if (n <= 0) return;  // empty input: gradients are exactly zero
+    WgJob& j = jl.wg.job[jl.wg.njobs++];
+    const int nb = cdiv(n, WG_ROWS);
+    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.d2 = d2; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
+    const float* src = partial + (size_t)jl.nslab * WG_SLAB;
+    jl.wg.nblocks += nb; jl.nslab += nb;
+    auto rd = [&](const float* s, float* dst, int len) {
+        RdJob& r = jl.rd.job[jl.rd.njobs++];
+        r.src = s; r.dst = dst; r.nparts = nb; r.stride = WG_SLAB; r.len = len; r.blk0 = jl.rdblk;
+        jl.rdblk += cdiv(len, EMB);
+    };
+    rd(src, gw, EMB * EMB);
+    if (gb) rd(src + EMB * EMB, gb, EMB);
+    if (g2) rd(src + EMB * EMB + EMB, g2, EMB);
+}
+// launch the weight-gradient jobs collected so far as one grouped kernel on `st`; slabs keep accumulating
+static int flush_wg(JobList& jl, hipStream_t st) {
+    if (jl.wg.nblocks > 0) {
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(256), 0, st, jl.wg);
+        LAUNCHCHK();
+    }
+    jl.wg.njobs = 0; jl.wg.nblocks = 0;
+    return 0;
+}
+static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int stride, int len) {
+    if (nparts <= 0) return;
+    RdJob& r = jl.rd.job[jl.rd.njobs++];
+    r.src = src; r.dst = dst; r.nparts = nparts; r.stride = stride; r.len = len; r.blk0 = jl.rdblk;
+    jl.rdblk += cdiv(len, EMB);
+}
+
+// Receiver-side gradient chain of one convolution, appended to `ch` whose tile 0 already holds dX' (masked):
+//   dZ1 = dX'pre W2^T (mask Z1) ; d x_recv = dZ1pre W1b^T ; dA = s2 * dZ1pre W1a^T ; dS = dA Wf^T
+static void conv_bwd_chain(Chain& ch, const float* p, const ConvIO& c) {
+    float* gxrecv = c.recv_left ? c.gXL : c.gXV;
+    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 1, c.gZ1, 0); s1.mask = c.Z1;
+    ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1) + EMB * EMB, 1, gxrecv, 1);
+    ChStage& s3 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 1, c.gA, 0); s3.so = p + poff(c.pbase + C_S2);
+    // dS = dA Wf^T, and element-wise from it the receiver-ordered half of the edge gradient (see k_edge_fwd):
+    //   dP_recv = s1*dS*N
+    ChStage& s4 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_WF), 1, c.gS, 0);
+    s4.em_s = p + poff(c.pbase + C_S1); s4.em_a = c.N; s4.em_out = c.recv_left ? c.gPL : c.gPR;
+}
+
+// sender-ordered half of the edge gradient, and the weight-gradient jobs of the whole convolution
+static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, const Work& w, JobList& jl, hipStream_t st) {
+    int rc;
+    const int nr = c.recv_left ? c.nl : c.nv;
+    const float* xrecv = c.recv_left ? c.xl : c.xv;
+    // the receiver-ordered half (dP_recv) came out of the chain's epilogue; sender-ordered half: dS rows + 16-B masks,
+    // which also yields Q, the per-sender share of d w_edge
+    EdgeArgs e = conv_edge_args(p, c, !c.recv_left);
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q; e.mask = c.mask; e.xpos = c.recv_left ? c.g->v2l : c.g->l2v;
+    if ((rc = launch_edge_bwd_send(e, c.ne, st))) return rc;
+    const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
+    float* gwe = grads + poff(c.pbase + C_WE);
+    add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
+    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
+    add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
+    add_wg(jl, c.S, nullptr, c.gA, seg, nullptr, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
+    // Q lives on the sender side: column-summed together with the sender-side projection's job
+    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.recv_left ? nullptr : c.Q, c.nl, grads + poff(c.pbase + C_WL),
+           grads + poff(c.pbase + C_BL), c.recv_left ? nullptr : gwe, w.partial);
+    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.recv_left ? c.Q : nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr,
+           c.recv_left ? gwe : nullptr, w.partial);
+    return 0;
+}
+
+static int embed1_wgrad(int f, const float* x, const float* p, int pb, const float* dy, const float* yact, float* partial,
+                        int n, int nblk, hipStream_t st) {
+    if (n <= 0) return 0;
+    const float *sh = p + poff(pb + E_SHIFT), *sc = p + poff(pb + E_SCALE);
+    if (f == 4) hipLaunchKernelGGL(k_embed1_wgrad<4>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
+    else if (f == 14) hipLaunchKernelGGL(k_embed1_wgrad<14>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
+    else hipLaunchKernelGGL(k_embed1_wgrad<6>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
+    LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out, float* d_scores,
+                  void* stream) {
+    if (n < 0 || (n > 0 && (!scores || !targets))) return GCNN_E_BADARG;
+    if (n == 0) {
+        if (loss_out) HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+        return 0;
+    }
+    hipLaunchKernelGGL(k_mse, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, targets, scale, loss_out, d_scores, n);
+    LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                  size_t workspace_floats, const float* d_scores, float* grads, void* stream) {
+    layout_init();
+    int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
+    if (rc) return rc;
+    if (!grads || (d->n_cuts > 0 && !d_scores)) return GCNN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Work w; carve(d, workspace, &w);
+    const Acts &A = w.a, &G = w.g;
+    JobList jl; memset(&jl, 0, sizeof(jl)); jl.wg.partial = w.partial;
+
+    // side streams: sw runs the weight-gradient groups and the final reduction, sc the cut-/constraint-row tail chains
+    const bool side = side_on();
+    hipStream_t sw = side ? g_side.s[0] : st, sc = side ? g_side.s[1] : st;
+    hipEvent_t ev = nullptr, ev_sc = nullptr, ev_sw = nullptr;
+    // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
+    if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
+    if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
+    if ((size_t)cdiv(d->n_cons, WG_ROWS) * 8 + (size_t)cdiv(d->n_vars, WG_ROWS) * 8 + (size_t)cdiv(d->n_cuts, WG_ROWS) * 8 > wg_slabs(d))
+        return GCNN_E_WORKSPACE;
+    ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+    struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
+        {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
+        {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
+        {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
+    // first embedding layer's weight gradient (VALU) + the reduction jobs of its slab
+    auto embed_first_layer = [&](int i, hipStream_t s) -> int {
+        int r = embed1_wgrad(em[i].f, em[i].x, p, em[i].pb, em[i].ge1, em[i].e1, w.emb_partial[i], em[i].n, w.emb_nblk[i], s);
+        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
+        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
+        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
+        return r;
+    };
+
+    // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
+    hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
+                       w.score_partial, d->n_cuts);
+    LAUNCHCHK();
+    add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), w.score_nblk, 2 * EMB, EMB);
+    add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), w.score_nblk, 2 * EMB, 1);
+    add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
+    {   // cut rows: readout -> conv v->k receiver chain
+        Chain ch(d->n_cuts);
+        ChStage& s0 = ch.gemm(G.O1, 0, p + poff(P_OUT), 1, G.Xk2, 0); s0.mask = A.Xk2;
+        conv_bwd_chain(ch, p, cv[2]);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    if ((rc = conv_backward_edges(p, grads, cv[2], w, jl, st))) return rc;
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sc, ev, st)))) return rc;
+    if ((rc = flush_wg(jl, sw))) return rc;   // readout + conv v->k weight gradients
+    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k; then the cut embedding's first layer
+        Chain ch(d->n_cuts);
+        ChStage& s0 = ch.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); s0.add = G.Xk; s0.mask = A.Xk;
+        ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
+        if ((rc = launch_chain(ch, sc)) || (rc = embed_first_layer(2, sc))) return rc;
+    }
+    {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain
+        Chain ch(d->n_vars);
+        ChStage& s0 = ch.gemm(G.PR3, 0, p + poff(P_CONV2 + C_WR), 1, G.Xv2, 0); s0.mask = A.Xv2;
+        conv_bwd_chain(ch, p, cv[1]);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)))) return rc;
+    if ((rc = flush_wg(jl, sw))) return rc;   // conv c->v weight gradients
+    {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver chain
+        Chain ch(d->n_cons);
+        ChStage& s0 = ch.gemm(G.PL2, 0, p + poff(P_CONV1 + C_WL), 1, G.Xc2, 0); s0.mask = A.Xc2;
+        conv_bwd_chain(ch, p, cv[0]);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    if ((rc = conv_backward_edges(p, grads, cv[0], w, jl, st))) return rc;
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sc, ev, st)))) return rc;
+    if ((rc = flush_wg(jl, sw))) return rc;   // conv v->c weight gradients
+    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c; then the constraint embedding's first layer
+        Chain ch(d->n_cons);
+        ChStage& s0 = ch.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); s0.add = G.Xc; s0.mask = A.Xc;
+        ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
+        if ((rc = launch_chain(ch, sc)) || (rc = embed_first_layer(0, sc))) return rc;
+        if (side && (rc = ev_record(sc, &ev_sc))) return rc;
+    }
+    {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v
+        Chain ch(d->n_vars);
+        ChStage& s0 = ch.gemm(G.PR2, 0, p + poff(P_CONV1 + C_WR), 1, G.Xv, 0);
+        s0.in_b = G.PR1; s0.tb = 1; s0.wb = ch.weight(p + poff(P_CONV0 + C_WR)); s0.add = G.Xv; s0.mask = A.Xv;
+        ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
+        if ((rc = launch_chain(ch, st))) return rc;
+    }
+    // tail on sw (needs all three tail chains): the embeddings' weight gradients, then the reduction of every slab
+    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sw, ev_sc, sc)))) return rc;
+    if ((rc = embed_first_layer(1, sw))) return rc;
+    for (int i = 0; i < 3; ++i)
+        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
+    if ((rc = flush_wg(jl, sw))) return rc;
+    if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
+    if (jl.rdblk > 0) {
+        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, sw, jl.rd);
+        LAUNCHCHK();
+    }
+    if (side && ((rc = ev_record(sw, &ev_sw)) || (rc = ev_wait(st, ev_sw, sw)))) return rc;
+    return 0;
+}
+
+// ---- PreNorm fitting statistics (model.py:394-423) ------------------------------------------------------------------
+extern "C" int gcnn_prenorm_stats(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                                  size_t workspace_floats, int32_t layer, double* out_mean_var, void* stream) {
+    layout_init();
+    int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
+    if (rc) return rc;
+    if (layer < 0 || layer > 10 || !out_mean_var) return GCNN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    Work w; carve(d, workspace, &w);
+    StatArgs a; memset(&a, 0, sizeof(a));
+    double count = 0.0;
+    int units = 1;
+    if (layer <= 4) {   // input layers: raw features, one unit per column (edge features: a single column)
+        const float* xs[5] = {cons_feats, cg->l_coef, var_feats, cut_feats, kg->l_coef};
+        const int ns[5] = {d->n_cons, d->n_cons_edges, d->n_vars, d->n_cuts, d->n_cut_edges};
+        const int fs[5] = {4, 1, 14, 6, 1};
+        a.src = ST_COLS; a.x = xs[layer]; a.n = ns[layer]; a.f = fs[layer]; units = a.f; count = (double)a.n;
+    } else {
+        ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
+        const ConvIO& c = cv[(layer - 5) >> 1];
+        if (((layer - 5) & 1) == 0) {   // feature_module_final's PreNorm: all E*64 joint pre-activations, one unit
+            a.src = ST_EDGE; a.n = c.ne; a.right = c.g->l_oth; a.coef = c.g->l_coef; a.pl = c.PL; a.pr = c.PR;
+            a.w_edge = p + poff(c.pbase + C_WE); a.e_shift = p + poff(c.pedge); a.e_scale = p + poff(c.pedge + 1);
+            if (c.ne > 0) {
+                hipLaunchKernelGGL(k_expand_ptr, dim3(std::min(cdiv(c.nl, 256), 1024)), dim3(256), 0, st, c.g->l_ptr, c.nl, w.stat_ids);
+                LAUNCHCHK();
+            }
+            a.left = w.stat_ids; count = (double)c.ne * EMB;
+        } else {                        // post_conv_module's PreNorm: all R*64 elements of the scatter-sum output, one unit
+            a.src = ST_FLAT; a.x = c.A; a.n = c.recv_left ? c.nl : c.nv; count = (double)a.n * EMB;
+        }
+    }
+    if (count <= 0.0) {   // nothing to absorb: mean 0, variance 0 (the caller skips empty batches)
+        HIPCHK(hipMemsetAsync(out_mean_var, 0, 2 * (size_t)units * sizeof(double), st));
+        return 0;
+    }
+    const int work = a.src == ST_EDGE ? cdiv(a.n, 16) : (a.src == ST_FLAT ? cdiv(a.n, 4) : cdiv(a.n, 256));
+    const int grid = std::max(1, std::min(work, ST_MAX_BLOCKS));
+    a.partial = w.stats;
+    a.mean = nullptr;
+    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, a); LAUNCHCHK();
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, st, w.stats, grid, units, count, out_mean_var); LAUNCHCHK();
+    a.mean = out_mean_var;
+    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, a); LAUNCHCHK();
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, st, w.stats, grid, units, count, out_mean_var + units); LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1, float beta2,
+                   float eps, const float* grad_scale, void* stream) {
+    if (n < 0 || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
+                       lr_t, beta1, beta2, eps, grad_scale);
+    LAUNCHCHK();
+    return 0;
+}

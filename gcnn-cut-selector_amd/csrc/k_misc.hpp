@@ -1,0 +1,189 @@
+#pragma once
+#include "gcnn_common.hpp"
+
+// ---------------------------------------------------------------------------------------------------------------
+// The loss head (model_trainer.py:271) and the gradient of the readout tail Dense(64->1) (model.py:208); the forward of
+// that Dense closes the last forward chain (CH_SCORE in k_chain.hpp).
+// ---------------------------------------------------------------------------------------------------------------
+// MSE head (model_trainer.py:271): loss = scale * sum_k (score_k - y_k)^2, d_score_k = 2*scale*(score_k - y_k).  One block.
+__global__ __launch_bounds__(256) void k_mse(const float* __restrict__ score, const float* __restrict__ target, float scale,
+                                             float* __restrict__ loss, float* __restrict__ d_score, int n) {
+    __shared__ float red[256];
+    float ls = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float d = score[k] - target[k];
+        ls = fmaf(d, d, ls);
+        if (d_score) d_score[k] = 2.f * d * scale;
+    }
+    red[threadIdx.x] = ls;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss) *loss = red[0] * scale;
+}
+
+// gradient of Dense(64->1): dO1pre[k][j] = ds_k*w2[j]*[O1[k][j] > 0]; dw2[j] = sum_k ds_k O1[k][j]; db2 = sum_k ds_k.
+// One block per SB_ROWS cuts; per-block partial slab [2*64]: dw2 partial, then db2 partial in element 64.
+#define SB_ROWS 64
+__global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_score, const float* __restrict__ o1,
+                                                   const float* __restrict__ w2, float* __restrict__ d_o1,
+                                                   float* __restrict__ partial, int n) {
+    __shared__ float red[4][EMB];
+    __shared__ float red2[256];
+    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const float wj = w2[col];
+    const int k0 = blockIdx.x * SB_ROWS, k1 = min(n, k0 + SB_ROWS);
+    float gw = 0.f;
+    for (int k = k0 + part; k < k1; k += 4) {
+        const float ds = d_score[k];
+        const float ov = o1[(size_t)k * EMB + col];
+        gw = fmaf(ds, ov, gw);
+        d_o1[(size_t)k * EMB + col] = ov > 0.f ? ds * wj : 0.f;  // gradient w.r.t. the pre-activation of out_1 (ReLU mask)
+    }
+    const int kk = k0 + threadIdx.x;
+    red[part][col] = gw; red2[threadIdx.x] = kk < k1 ? d_score[kk] : 0.f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red2[threadIdx.x] += red2[threadIdx.x + s];
+        __syncthreads();
+    }
+    float* slab = partial + (size_t)blockIdx.x * 2 * EMB;
+    if (threadIdx.x < EMB) slab[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) slab[EMB] = red2[0];
+}
+
+// Keras-form Adam (model_trainer.py:131,273): eps outside the bias-corrected sqrt.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int n, float lr_t, float b1, float b2, float eps,
+                                              const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PreNorm fitting statistics (PreNormLayer.update_params, model.py:394-423): per batch, the population mean and the
+// mean squared deviation of a layer's input, per unit.  Offline path (pretraining), so: two passes (mean, then centred
+// second moment), double accumulators, per-block partials summed in a fixed order.  Three element sources:
+//   ST_COLS  a dense [n, f] matrix, one unit per column            (the five input PreNorm layers)
+//   ST_FLAT  a dense [n, 64] matrix, ONE unit over all elements     (post_conv_module, model.py:503, 570)
+//   ST_EDGE  the joint edge pre-activations J_e[64] = PL[l_e] + c_e*w + PR[v_e], ONE unit (feature_module_final's
+//            PreNorm, model.py:498, 563-565) -- never materialised
+// ---------------------------------------------------------------------------------------------------------------
+enum { ST_COLS = 0, ST_FLAT = 1, ST_EDGE = 2 };
+#define ST_MAX_UNITS 16
+#define ST_MAX_BLOCKS 1024
+struct StatArgs {
+    int src; int n; int f;                  // rows (or edges), columns/units
+    const float* x;                         // ST_COLS / ST_FLAT
+    const int* left; const int* right; const float* coef; const float* pl; const float* pr; const float* w_edge;
+    const float* e_shift; const float* e_scale;   // ST_EDGE (by-left order arrays: left id via seg search is avoided: `left` is explicit)
+    const double* mean;                     // pass 2: centre (device, [units]); nullptr in pass 1
+    double* partial;                        // [gridDim.x][units]
+};
+
+__global__ __launch_bounds__(256) void k_stats(StatArgs a) {
+    __shared__ double red[256];
+    const int units = a.src == ST_COLS ? a.f : 1;
+    double acc[ST_MAX_UNITS];
+#pragma unroll
+    for (int u = 0; u < ST_MAX_UNITS; ++u) acc[u] = 0.0;
+    if (a.src == ST_COLS) {
+        for (int r = blockIdx.x * 256 + threadIdx.x; r < a.n; r += gridDim.x * 256)
+#pragma unroll
+            for (int u = 0; u < ST_MAX_UNITS; ++u)
+                if (u < a.f) {
+                    const double v = (double)a.x[(size_t)r * a.f + u];
+                    if (a.mean) { const double d = v - a.mean[u]; acc[u] += d * d; } else acc[u] += v;
+                }
+    } else if (a.src == ST_FLAT) {
+        const double mu = a.mean ? a.mean[0] : 0.0;
+        const size_t total = (size_t)a.n * EMB;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const double v = (double)a.x[i];
+            if (a.mean) { const double d = v - mu; acc[0] += d * d; } else acc[0] += v;
+        }
+    } else {
+        const double mu = a.mean ? a.mean[0] : 0.0;
+        const float esh = *a.e_shift, esc = *a.e_scale;
+        const int ch = (threadIdx.x & 15) * 4;
+        const float4 w = *(const float4*)(a.w_edge + ch);
+        for (int e = blockIdx.x * 16 + (threadIdx.x >> 4); e < a.n; e += gridDim.x * 16) {
+            const float c = (a.coef[e] + esh) * esc;
+            const float4 p = *(const float4*)(a.pl + (size_t)a.left[e] * EMB + ch);
+            const float4 q = *(const float4*)(a.pr + (size_t)a.right[e] * EMB + ch);
+            const float jv[4] = {jointf(p.x, __fmul_rn(c, w.x), q.x), jointf(p.y, __fmul_rn(c, w.y), q.y),
+                                 jointf(p.z, __fmul_rn(c, w.z), q.z), jointf(p.w, __fmul_rn(c, w.w), q.w)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double v = (double)jv[k];
+                if (a.mean) { const double d = v - mu; acc[0] += d * d; } else acc[0] += v;
+            }
+        }
+    }
+    for (int u = 0; u < units; ++u) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < ST_MAX_UNITS; ++k) if (k == u) v = acc[k];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.partial[(size_t)blockIdx.x * units + u] = red[0];
+        __syncthreads();
+    }
+}
+// out[u] = (sum over blocks of partial[b][u]) / count      (one block, fixed order)
+__global__ __launch_bounds__(64) void k_stats_final(const double* __restrict__ partial, int nblocks, int units, double count,
+                                                    double* __restrict__ out) {
+    const int u = threadIdx.x;
+    if (u >= units) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * units + u];
+    out[u] = s / count;
+}
+// expand a by-left CSR pointer into explicit left ids (pretraining only)
+__global__ void k_expand_ptr(const int* __restrict__ ptr, int n_seg, int* __restrict__ ids) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n_seg; r += gridDim.x * blockDim.x)
+        for (int e = ptr[r]; e < ptr[r + 1]; ++e) ids[e] = r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// graph plan kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_iota(int* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
+}
+// sorted keys -> segment offsets: ptr[k] = first position whose key >= k, ptr[n_seg] = n
+__global__ void k_seg_offsets(const int* __restrict__ keys, int n, int n_seg, int* __restrict__ ptr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+        const int lo = i == 0 ? -1 : max(keys[i - 1], -1);
+        const int hi = i == n ? n_seg : min(keys[i], n_seg);
+        for (int k = lo + 1; k <= hi; ++k) ptr[k] = i;
+    }
+}
+// inv[perm[i]] = i
+__global__ void k_invert_perm(const int* __restrict__ perm, int n, int* __restrict__ inv) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) inv[perm[i]] = i;
+}
+// out[i] = inv[perm[i]]
+__global__ void k_compose_perm(const int* __restrict__ perm, const int* __restrict__ inv, int n, int* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = inv[perm[i]];
+}
+__global__ void k_gather_edges(const int* __restrict__ perm, const int* __restrict__ other, const float* __restrict__ coef,
+                               int n, int* __restrict__ oth_out, float* __restrict__ coef_out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int e = perm[i];
+        oth_out[i] = other[e]; coef_out[i] = coef[e];
+    }
+}
+
