@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture the step once and replay it as a hipGraph (measured: no faster than eager issue -- the GPU-side dependency chain is the limit, not the host)")
     return ap.parse_args()
 
 
@@ -153,7 +154,7 @@ def main():
 
     from gcnn_cut_selector_amd import synthetic
     from gcnn_cut_selector_amd.model import GCNN
-    from gcnn_cut_selector_amd.trainer import Adam, TrainState, train_step
+    from gcnn_cut_selector_amd.trainer import Adam, GraphedTrainStep, TrainState, train_step
 
     model = GCNN(device=dev, seed=0)
     if group is not None:  # replicate rank 0's initial weights
@@ -167,6 +168,15 @@ def main():
 
     def step():
         return train_step(model, batch, targets, opt, ts, process_group=group)
+
+    launch = "eager"
+    if args.graph:
+        try:  # the whole step (3 streams, ~35 launches, the all-reduce) as one hipGraph replay
+            step = GraphedTrainStep(model, batch, targets, opt, ts, process_group=group)
+            launch = "hipGraph replay"
+        except Exception as exc:  # capture not possible (e.g. a collective that cannot be captured): stay eager
+            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -198,6 +208,7 @@ def main():
         "config": {"workload": f"{args.problem}-500 rows x batch {args.batch} per GPU (BASELINE configs[1])"
                    if args.problem == "setcov" else f"{args.problem} x batch {args.batch} per GPU",
                    "step": "fwd + mse + bwd" + (" + rccl all-reduce(flat grads)" if group is not None else "") + " + adam",
+                   "launch": launch,
                    "global_batch": args.batch * world, "edges_per_step": edges_total, "n_cons": batch.dims.n_cons,
                    "n_vars": batch.dims.n_vars, "n_cuts": batch.dims.n_cuts, "parallelism": f"dp{world}",
                    "final_loss": float(loss)},

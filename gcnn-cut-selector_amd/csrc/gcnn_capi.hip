@@ -773,3 +773,15 @@ extern "C" int gcnn_adam_step(float* params, const float* grads, float* m, float
     LAUNCHCHK();
     return 0;
 }
+
+extern "C" int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
+                                  const float* grad_scale, void* stream) {
+    if (n < 0 || !opt_state || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, opt_state);
+    LAUNCHCHK();
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam_dev, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
+                       opt_state, grad_scale);
+    LAUNCHCHK();
+    return 0;
+}

@@ -67,6 +67,27 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
         p[i] -= lr_t * mi / (sqrtf(vi) + eps);
     }
 }
+// The same update with every hyper-parameter and the step counter resident on the device, so that a captured hipGraph
+// can be replayed step after step: opt = {lr, beta1, beta2, eps, t (step count), lr_t}.  k_adam_tick advances t and
+// computes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in double; k_adam_dev applies it.
+__global__ void k_adam_tick(float* __restrict__ opt) {
+    const double t = (double)opt[4] + 1.0;
+    opt[4] = (float)t;
+    opt[5] = (float)((double)opt[0] * sqrt(1.0 - pow((double)opt[2], t)) / (1.0 - pow((double)opt[1], t)));
+}
+__global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int n, const float* __restrict__ opt,
+                                                  const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    const float b1 = opt[1], b2 = opt[2], eps = opt[3], lr_t = opt[5];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // PreNorm fitting statistics (PreNormLayer.update_params, model.py:394-423): per batch, the population mean and the

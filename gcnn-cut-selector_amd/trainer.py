@@ -43,6 +43,7 @@ class Adam:
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         self.iterations = 0
         self.m = self.v = None
+        self._dev = None   # device-resident {lr, b1, b2, eps, t, lr_t} for graph replay
 
     def _lr(self):
         return float(self.learning_rate() if callable(self.learning_rate) else self.learning_rate)
@@ -58,6 +59,26 @@ class Adam:
             _lib.check(_lib.lib().gcnn_adam_step(_ptr(flat), _ptr(flat_grad), _ptr(self.m), _ptr(self.v), flat.numel(),
                                                  lr_t, self.beta_1, self.beta_2, self.epsilon, _ptr(grad_scale),
                                                  _stream(flat.device)), "gcnn_adam_step")
+
+    def apply_flat_dev(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None):
+        """The same update with hyper-parameters and step counter resident on the device (gcnn_adam_step_dev): nothing
+        step-dependent crosses the host, so the call can sit inside a captured hipGraph and be replayed."""
+        flat = model.flat_parameters.detach()
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        if self._dev is None:
+            self._dev = torch.tensor([self._lr(), self.beta_1, self.beta_2, self.epsilon, float(self.iterations), 0.0],
+                                     dtype=torch.float32, device=flat.device)
+        with torch.cuda.device(flat.device):
+            _lib.check(_lib.lib().gcnn_adam_step_dev(_ptr(flat), _ptr(flat_grad), _ptr(self.m), _ptr(self.v), flat.numel(),
+                                                     _ptr(self._dev), _ptr(grad_scale), _stream(flat.device)),
+                       "gcnn_adam_step_dev")
+
+    def sync_from_device(self):
+        """After graph replays: pull the step counter back; push the (possibly changed) learning rate."""
+        if self._dev is not None:
+            self.iterations = int(self._dev[4].item())
+            self._dev[0] = self._lr()
 
     def apply_gradients(self, model: GCNN):
         """After `loss.backward()`: update from `model.flat_parameters.grad` (the reference's
@@ -81,7 +102,7 @@ class TrainState:
 
 
 def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam | None, state: TrainState,
-               process_group=None):
+               process_group=None, device_optimizer=False):
     """One training step on a prepared batch: forward + MSE + backward (+ all-reduce) (+ Adam).  Returns (loss, scores).
 
     Single GPU: loss = mean over this batch's cuts (model_trainer.py:271).  Data parallel (`process_group` given): each
@@ -96,7 +117,7 @@ def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam
         model._backward_into(flat, batch, ws, d_scores, state.grads)
         model._give_workspace(ws)
         if optimizer is not None:
-            optimizer.apply_flat(model, state.grads)
+            (optimizer.apply_flat_dev if device_optimizer else optimizer.apply_flat)(model, state.grads)
         return loss, scores
     import torch.distributed as dist
     loss, d_scores = mse_loss(scores, targets, 1.0)  # local SUM of squared errors
@@ -106,8 +127,42 @@ def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam
     dist.all_reduce(state.buf, op=dist.ReduceOp.SUM, group=process_group)
     torch.reciprocal(state.count, out=state.inv_count)
     if optimizer is not None:
-        optimizer.apply_flat(model, state.grads, grad_scale=state.inv_count)
+        (optimizer.apply_flat_dev if device_optimizer else optimizer.apply_flat)(model, state.grads, grad_scale=state.inv_count)
     return loss, scores
+
+
+class GraphedTrainStep:
+    """One training step on a FIXED prepared batch, captured once into a hipGraph and replayed.
+
+    A step is ~35 kernel launches plus event edges between three streams; issued eagerly the host needs ~0.3-0.5 ms for
+    them, as long as the GPU needs to run them.  Capture (torch.cuda.CUDAGraph over the same `train_step`, whose C side
+    forks/joins its side streams with events, which capture turns into parallel graph branches) removes the host from the
+    loop.  Everything step-dependent lives on the device (Adam's step counter and learning rate: `Adam.apply_flat_dev`).
+    The graph is tied to the batch's buffers and sizes: use it when batches have a fixed shape / are replayed (benchmarks,
+    fixed-capacity loaders); variable-shape training uses the eager `train_step`."""
+
+    def __init__(self, model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam | None, state: TrainState,
+                 process_group=None, warmup=2):
+        self.optimizer = optimizer
+        args = (model, batch, targets, optimizer, state, process_group, True)
+        cur = torch.cuda.current_stream(model.device)
+        side = torch.cuda.Stream(device=model.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):           # eager warm-up: lazy HIP state (streams, events, attributes) and buffers
+            for _ in range(warmup):
+                train_step(*args)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(model.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.scores = train_step(*args)
+        self.steps = 0
+
+    def __call__(self):
+        self.graph.replay()
+        self.steps += 1
+        return self.loss, self.scores
+
 
 
 def ranking_fraction(pred: np.ndarray, true: np.ndarray) -> float:

@@ -146,6 +146,12 @@ int gcnn_prenorm_stats(const gcnn_dims* dims, const float* params, const float* 
 int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1,
                    float beta2, float eps, const float* grad_scale, void* stream);
 
+/* The same update with hyper-parameters and step counter on the device, so that a captured hipGraph of a whole training
+ * step can be replayed: opt_state = {lr, beta1, beta2, eps, t, lr_t} (6 floats, device).  Each call advances t by one and
+ * recomputes lr_t; the caller changes lr (the plateau schedule of model_trainer.py:177-179) by writing opt_state[0]. */
+int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
+                       const float* grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

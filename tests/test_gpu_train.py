@@ -147,3 +147,42 @@ def test_full_size_batching_invariance_determinism_and_finite_grads(dev):
     m._forward_into(flat, batch, ws)
     m._backward_into(flat, batch, ws, 2 * d, gb)
     np.testing.assert_allclose(gb.cpu().numpy(), 2 * ga.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ga.abs().max()))
+
+
+def test_graphed_step_matches_eager_steps(dev):
+    """A captured hipGraph of the whole step (3 streams, device-resident Adam state) replayed == the same steps issued
+    eagerly: bitwise, because the kernels, their order of summation and the device-side Adam arithmetic are identical."""
+    from gcnn_cut_selector_amd.trainer import Adam, GraphedTrainStep, TrainState, train_step
+    state, y, _ = synthetic.make_batch("combauc", 4)
+    finals = []
+    for graphed in (False, True):
+        m, _ = _model(30, dev)
+        batch = m.prepare(state)
+        yt = torch.as_tensor(y).to(dev)
+        opt, ts = Adam(1e-3), TrainState(m)
+        if graphed:
+            step = GraphedTrainStep(m, batch, yt, opt, ts, warmup=2)     # two eager warm-up steps, then capture (no step)
+            for _ in range(3):
+                loss, _ = step()
+        else:
+            for _ in range(5):
+                loss, _ = train_step(m, batch, yt, opt, ts, device_optimizer=True)
+        torch.cuda.synchronize()
+        opt.sync_from_device()
+        assert opt.iterations == 5
+        finals.append((float(loss), np.concatenate([w.reshape(-1) for w in m.get_weights()])))
+    assert finals[0][0] == finals[1][0]
+    assert np.array_equal(finals[0][1], finals[1][1])
+
+
+def test_device_resident_adam_matches_host_parameterised_adam(dev):
+    from gcnn_cut_selector_amd.trainer import Adam
+    m1, _ = _model(31, dev)
+    m2, _ = _model(31, dev)
+    g = torch.randn_like(m1.flat_parameters.detach()) * m1._trainable_mask
+    o1, o2 = Adam(3e-4), Adam(3e-4)
+    for _ in range(4):
+        o1.apply_flat(m1, g)
+        o2.apply_flat_dev(m2, g)
+    np.testing.assert_allclose(m1.flat_parameters.detach().cpu().numpy(), m2.flat_parameters.detach().cpu().numpy(),
+                               rtol=2e-6, atol=1e-8)
