@@ -53,6 +53,7 @@ SIGNATURES = {
     "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P]),
     "gcnn_prenorm_stats": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _I, _P, _P]),
     "gcnn_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
+    "gcnn_ranking_metric": (C.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P]),
     "gcnn_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _P]),
 }
 

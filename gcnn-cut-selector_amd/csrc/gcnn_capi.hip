@@ -785,3 +785,18 @@ extern "C" int gcnn_adam_step_dev(float* params, const float* grads, float* m, f
     LAUNCHCHK();
     return 0;
 }
+
+// ---- ranking-prefix accuracy (model_trainer.py:280-302) on the device ------------------------------------------------
+extern "C" int gcnn_ranking_metric(const float* pred, const float* truth, const int32_t* offsets, int32_t n_samples,
+                                   int32_t max_cuts, const float* fractions, int32_t n_fractions, float* acc,
+                                   float* frac_out, const float* loss_in, float loss_weight, float* loss_acc, void* stream) {
+    if (n_samples < 0 || n_fractions < 0 || (n_samples > 0 && (!pred || !truth || !offsets))) return GCNN_E_BADARG;
+    if (n_fractions > 0 && (!fractions || !acc)) return GCNN_E_BADARG;
+    if (loss_acc && !loss_in) return GCNN_E_BADARG;
+    if (max_cuts > RK_MAX) return GCNN_E_WORKSPACE;   // a sample with more cuts than the LDS sort holds: use the host metric
+    if (n_samples == 0) return 0;
+    hipLaunchKernelGGL(k_ranking, dim3(n_samples), dim3(256), 0, (hipStream_t)stream, pred, truth, offsets, fractions,
+                       n_fractions, acc, frac_out, loss_in, loss_weight, loss_acc);
+    LAUNCHCHK();
+    return 0;
+}

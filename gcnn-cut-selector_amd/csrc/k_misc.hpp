@@ -90,6 +90,64 @@ __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const f
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Ranking-prefix accuracy (model_trainer.py:280-302, model_tester.py:205-224) on the device.  Per sample: rank the cuts
+// by predicted and by true improvement -- descending, ties in index order, which is what Python's stable
+// sorted(..., reverse=True) yields -- and take the first position where the two rankings differ, over the number of cuts.
+// One block per sample; both (value, index) lists are sorted in LDS with a bitonic network under the total order
+// "larger value first, then smaller index", whose result IS the stable order.  acc[f] += [frac >= fractions[f]]
+// (integer-valued float adds: exact and order-independent), frac_out[s] = frac.
+// ---------------------------------------------------------------------------------------------------------------
+#define RK_MAX 4096
+__device__ __forceinline__ bool rk_before(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+__global__ __launch_bounds__(256) void k_ranking(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                 const int* __restrict__ offsets, const float* __restrict__ fractions,
+                                                 int nfrac, float* __restrict__ acc, float* __restrict__ frac_out,
+                                                 const float* __restrict__ loss_in, float loss_weight, float* __restrict__ loss_acc) {
+    __shared__ float v[2][RK_MAX];
+    __shared__ int ix[2][RK_MAX];
+    __shared__ int first_dev;
+    const int s = blockIdx.x, beg = offsets[s], n = offsets[s + 1] - beg;
+    if (s == 0 && threadIdx.x == 0 && loss_acc) *loss_acc += *loss_in * loss_weight;
+    if (n <= 0) { if (threadIdx.x == 0 && frac_out) frac_out[s] = 0.f; return; }
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const bool in = i < n;
+        v[0][i] = in ? pred[beg + i] : -INFINITY; v[1][i] = in ? truth[beg + i] : -INFINITY;
+        ix[0][i] = ix[1][i] = in ? i : 0x7fffffff;   // padding sorts last in both lists
+    }
+    if (threadIdx.x == 0) first_dev = n;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const float vi = v[a][i], vp = v[a][p];
+                        const int ii = ix[a][i], ip = ix[a][p];
+                        const bool swap = up ? rk_before(vp, ip, vi, ii) : rk_before(vi, ii, vp, ip);
+                        if (swap) { v[a][i] = vp; v[a][p] = vi; ix[a][i] = ip; ix[a][p] = ii; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (ix[0][i] != ix[1][i]) atomicMin(&first_dev, i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float frac = (float)first_dev / (float)n;
+        if (frac_out) frac_out[s] = frac;
+        for (int f = 0; f < nfrac; ++f)
+            if (frac >= fractions[f]) atomicAdd(&acc[f], 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // PreNorm fitting statistics (PreNormLayer.update_params, model.py:394-423): per batch, the population mean and the
 // mean squared deviation of a layer's input, per unit.  Offline path (pretraining), so: two passes (mean, then centred
 // second moment), double accumulators, per-block partials summed in a fixed order.  Three element sources:

@@ -174,10 +174,32 @@ def ranking_fraction(pred: np.ndarray, true: np.ndarray) -> float:
     return (int(np.argmax(diff)) if diff.any() else len(pr)) / len(pr)
 
 
+def ranking_metric(pred: torch.Tensor, true: torch.Tensor, n_cuts, fractions_dev: torch.Tensor, acc: torch.Tensor,
+                   loss: torch.Tensor | None = None, loss_acc: torch.Tensor | None = None):
+    """Device-side ranking-prefix accuracy (gcnn_ranking_metric): acc[f] += #samples with frac >= fractions[f]; optionally
+    loss_acc += loss * total_cuts (the cut-weighted loss of model_trainer.py:304).  Returns per-sample fractions (device)."""
+    n_cuts = np.asarray(n_cuts, dtype=np.int64).reshape(-1)
+    offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(n_cuts)]).astype(np.int32)).to(pred.device, non_blocking=True)
+    frac = torch.empty(len(n_cuts), dtype=torch.float32, device=pred.device)
+    with torch.cuda.device(pred.device):
+        _lib.check(_lib.lib().gcnn_ranking_metric(_ptr(pred), _ptr(true), _ptr(offsets), len(n_cuts),
+                                                  int(n_cuts.max()) if len(n_cuts) else 0, _ptr(fractions_dev),
+                                                  fractions_dev.numel(), _ptr(acc), _ptr(frac), _ptr(loss),
+                                                  float(n_cuts.sum()), _ptr(loss_acc), _stream(pred.device)),
+                   "gcnn_ranking_metric")
+    return frac
+
+
 def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | None = None):
     """Counterpart of model_trainer.process (model_trainer.py:239-316).  `dataloader` yields the 11-tuples of
-    `utils.load_batch` (per-sample count vectors + improvements).  Returns (cut-weighted mean loss, accuracy per fraction)."""
-    mean_loss, mean_acc = 0.0, np.zeros(len(fractions))
+    `utils.load_batch` (per-sample count vectors + improvements).  Returns (cut-weighted mean loss, accuracy per fraction).
+    Loss and ranking accuracy accumulate ON THE DEVICE; the host reads them once at the end (no per-batch sync)."""
+    dev = model.device
+    fractions = np.asarray(fractions, dtype=np.float32)
+    frac_dev = torch.from_numpy(fractions).to(dev)
+    acc_dev = torch.zeros(len(fractions), dtype=torch.float32, device=dev)
+    loss_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+    host_acc, host_loss = np.zeros(len(fractions)), 0.0   # samples too large for the device metric (> 4096 cuts)
     n_samples = cut_count = 0
     state = TrainState(model) if optimizer is not None else None
     for batch in dataloader:
@@ -186,28 +208,30 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | No
         inputs = (c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)), int(n_cuts.sum()))
         try:
             prepared = model.prepare(inputs)
-            y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(model.device)
+            y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(dev, non_blocking=True)
             if optimizer is not None:
                 loss, predictions = train_step(model, prepared, y, optimizer, state)
             else:
                 with torch.no_grad():
                     predictions = model(prepared, False)
                 loss, _ = mse_loss(predictions, y, want_grad=False)
-            pred, true = predictions.detach().cpu().numpy(), np.asarray(improvements)
-            acc = np.zeros(len(fractions))
-            start = 0
-            for nk in n_cuts:
-                frac = ranking_fraction(pred[start:start + nk], true[start:start + nk])
-                acc += frac >= fractions
-                start += nk
             total = int(n_cuts.sum())
-            mean_loss += float(loss) * total
-            mean_acc += acc
+            if len(n_cuts) and n_cuts.max() <= 4096:
+                ranking_metric(predictions.detach().as_subclass(torch.Tensor), y, n_cuts, frac_dev, acc_dev, loss, loss_dev)
+            else:
+                pred, true = predictions.detach().cpu().numpy(), np.asarray(improvements)
+                start = 0
+                for nk in n_cuts:
+                    host_acc += ranking_fraction(pred[start:start + nk], true[start:start + nk]) >= fractions
+                    start += nk
+                host_loss += float(loss) * total
             n_samples += len(n_cuts)
             cut_count += total
         except torch.OutOfMemoryError:  # the reference skips batches that exhaust memory (model_trainer.py:308-311)
             print("WARNING: batch skipped.")
-    return mean_loss / max(cut_count, 1), mean_acc / max(n_samples, 1)
+    mean_loss = (float(loss_dev.item()) + host_loss) / max(cut_count, 1)
+    mean_acc = (acc_dev.cpu().numpy().astype(np.float64) + host_acc) / max(n_samples, 1)
+    return mean_loss, mean_acc
 
 
 def pretrain(model: GCNN, dataloader):

@@ -152,6 +152,16 @@ int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_
 int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
                        const float* grad_scale, void* stream);
 
+/* ---- ranking-prefix accuracy on the device: model_trainer.py:280-302 / model_tester.py:205-224 ----------------------
+ * Per sample s (cuts offsets[s] .. offsets[s+1]-1 of the stacked vectors): rank by pred and by truth, descending, ties in
+ * index order (Python's stable sorted(reverse=True)); frac = first differing position / #cuts (1 if none).
+ * acc[f] += [frac >= fractions[f]] (accumulates across calls); frac_out[s] = frac (optional).  max_cuts = largest sample
+ * (host value, <= 4096, else GCNN_E_WORKSPACE).  Optionally also accumulates the cut-weighted loss of
+ * model_trainer.py:304: loss_acc[0] += loss_in[0] * loss_weight. */
+int gcnn_ranking_metric(const float* pred, const float* truth, const int32_t* offsets, int32_t n_samples,
+                        int32_t max_cuts, const float* fractions, int32_t n_fractions, float* acc, float* frac_out,
+                        const float* loss_in, float loss_weight, float* loss_acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,24 @@ def test_device_resident_adam_matches_host_parameterised_adam(dev):
         o2.apply_flat_dev(m2, g)
     np.testing.assert_allclose(m1.flat_parameters.detach().cpu().numpy(), m2.flat_parameters.detach().cpu().numpy(),
                                rtol=2e-6, atol=1e-8)
+
+
+def test_device_ranking_metric_matches_reference_semantics(dev):
+    """gcnn_ranking_metric vs the oracle's restatement of model_trainer.py:288-301, with many ties and ragged sample sizes."""
+    from gcnn_cut_selector_amd.trainer import ranking_metric
+    rng = np.random.default_rng(0)
+    n_cuts = np.array([1, 2, 3, 17, 64, 65, 100, 257, 1000, 4096, 5])
+    pred = [rng.integers(0, 6, n).astype(np.float32) for n in n_cuts]
+    true = [p.copy() for p in pred]
+    for p, t in zip(pred, true):             # perturb a suffix so prefixes of varying length agree
+        k = int(rng.integers(0, len(p) + 1))
+        t[k:] = rng.integers(0, 6, len(p) - k)
+    fractions = np.array([0.25, 0.5, 0.75, 1.0], np.float32)
+    acc = torch.zeros(4, device=dev)
+    loss, loss_acc = torch.tensor([0.5], device=dev), torch.zeros(1, device=dev)
+    frac = ranking_metric(torch.from_numpy(np.concatenate(pred)).to(dev), torch.from_numpy(np.concatenate(true)).to(dev),
+                          n_cuts, torch.from_numpy(fractions).to(dev), acc, loss, loss_acc)
+    want = np.array([O.ranking_fraction(p, t) for p, t in zip(pred, true)])
+    np.testing.assert_allclose(frac.cpu().numpy(), want, rtol=1e-6)
+    np.testing.assert_array_equal(acc.cpu().numpy(), (want[:, None] >= fractions[None, :]).sum(0))
+    assert float(loss_acc) == 0.5 * n_cuts.sum()
