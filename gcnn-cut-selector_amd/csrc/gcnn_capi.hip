@@ -147,7 +147,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 1; }
+int gcnn_abi_version(void) { return 2; }
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -613,11 +613,13 @@ extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t 
 
 extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
-                  size_t workspace_floats, const float* d_scores, float* grads, void* stream) {
+                  size_t workspace_floats, const float* d_scores, float* grads, float* cut_count_out, void* stream) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
     if (!grads || (d->n_cuts > 0 && !d_scores)) return GCNN_E_BADARG;
+    // data-parallel callers all-reduce [gradients | cut count]: the count is stored by the first backward kernel
+    if (cut_count_out && d->n_cuts <= 0) HIPCHK(hipMemsetAsync(cut_count_out, 0, sizeof(float), (hipStream_t)stream));
     hipStream_t st = (hipStream_t)stream;
     Work w; carve(d, workspace, &w);
     const Acts &A = w.a, &G = w.g;
@@ -648,7 +650,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
 
     // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
     hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
-                       w.score_partial, d->n_cuts);
+                       w.score_partial, cut_count_out, d->n_cuts);
     LAUNCHCHK();
     add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), w.score_nblk, 2 * EMB, EMB);
     add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), w.score_nblk, 2 * EMB, 1);
@@ -765,23 +767,23 @@ extern "C" int gcnn_prenorm_stats(const gcnn_dims* d, const float* p, const floa
 }
 
 extern "C" int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1, float beta2,
-                   float eps, const float* grad_scale, void* stream) {
+                   float eps, const float* grad_scale, int32_t scale_is_divisor, void* stream) {
     if (n < 0 || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_adam, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                       lr_t, beta1, beta2, eps, grad_scale);
+                       lr_t, beta1, beta2, eps, grad_scale, scale_is_divisor);
     LAUNCHCHK();
     return 0;
 }
 
 extern "C" int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
-                                  const float* grad_scale, void* stream) {
+                                  const float* grad_scale, int32_t scale_is_divisor, void* stream) {
     if (n < 0 || !opt_state || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, opt_state);
     LAUNCHCHK();
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_adam_dev, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
-                       opt_state, grad_scale);
+                       opt_state, grad_scale, scale_is_divisor);
     LAUNCHCHK();
     return 0;
 }

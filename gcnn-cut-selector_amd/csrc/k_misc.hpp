@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_mse(const float* __restrict__ score, co
 #define SB_ROWS 64
 __global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_score, const float* __restrict__ o1,
                                                    const float* __restrict__ w2, float* __restrict__ d_o1,
-                                                   float* __restrict__ partial, int n) {
+                                                   float* __restrict__ partial, float* __restrict__ count_out, int n) {
     __shared__ float red[4][EMB];
     __shared__ float red2[256];
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -52,13 +52,14 @@ __global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_s
     float* slab = partial + (size_t)blockIdx.x * 2 * EMB;
     if (threadIdx.x < EMB) slab[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (threadIdx.x == 0) slab[EMB] = red2[0];
+    if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = (float)n;
 }
 
 // Keras-form Adam (model_trainer.py:131,273): eps outside the bias-corrected sqrt.
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int n, float lr_t, float b1, float b2, float eps,
-                                              const float* __restrict__ gscale) {
-    const float gs = gscale ? *gscale : 1.f;
+                                              const float* __restrict__ gscale, int recip) {
+    const float gs = gscale ? (recip ? 1.f / *gscale : *gscale) : 1.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float gi = g[i] * gs;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -77,8 +78,8 @@ __global__ void k_adam_tick(float* __restrict__ opt) {
 }
 __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int n, const float* __restrict__ opt,
-                                                  const float* __restrict__ gscale) {
-    const float gs = gscale ? *gscale : 1.f;
+                                                  const float* __restrict__ gscale, int recip) {
+    const float gs = gscale ? (recip ? 1.f / *gscale : *gscale) : 1.f;
     const float b1 = opt[1], b2 = opt[2], eps = opt[3], lr_t = opt[5];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float gi = g[i] * gs;

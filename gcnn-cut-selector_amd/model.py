@@ -283,12 +283,12 @@ class GCNN:
                                                int(save), _stream(self.device)), "gcnn_forward")
         return scores
 
-    def _backward_into(self, flat, batch, ws, d_scores, grads):
+    def _backward_into(self, flat, batch, ws, d_scores, grads, count_slot=None):
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().gcnn_backward(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
                                                 _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
                                                 C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(d_scores),
-                                                _ptr(grads), _stream(self.device)), "gcnn_backward")
+                                                _ptr(grads), _ptr(count_slot), _stream(self.device)), "gcnn_backward")
 
     def call(self, inputs, training=False):
         """GCNN.call (model.py:257-300): flat fp32 scores, one per candidate cut.  `training` is accepted and ignored

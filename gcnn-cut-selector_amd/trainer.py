@@ -48,7 +48,8 @@ class Adam:
     def _lr(self):
         return float(self.learning_rate() if callable(self.learning_rate) else self.learning_rate)
 
-    def apply_flat(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None):
+    def apply_flat(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None, divide=False):
+        """grad_scale: optional device scalar multiplying (divide=False) or dividing (divide=True) every gradient."""
         flat = model.flat_parameters.detach()
         if self.m is None:
             self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
@@ -58,9 +59,9 @@ class Adam:
         with torch.cuda.device(flat.device):
             _lib.check(_lib.lib().gcnn_adam_step(_ptr(flat), _ptr(flat_grad), _ptr(self.m), _ptr(self.v), flat.numel(),
                                                  lr_t, self.beta_1, self.beta_2, self.epsilon, _ptr(grad_scale),
-                                                 _stream(flat.device)), "gcnn_adam_step")
+                                                 int(divide), _stream(flat.device)), "gcnn_adam_step")
 
-    def apply_flat_dev(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None):
+    def apply_flat_dev(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None, divide=False):
         """The same update with hyper-parameters and step counter resident on the device (gcnn_adam_step_dev): nothing
         step-dependent crosses the host, so the call can sit inside a captured hipGraph and be replayed."""
         flat = model.flat_parameters.detach()
@@ -71,7 +72,7 @@ class Adam:
                                      dtype=torch.float32, device=flat.device)
         with torch.cuda.device(flat.device):
             _lib.check(_lib.lib().gcnn_adam_step_dev(_ptr(flat), _ptr(flat_grad), _ptr(self.m), _ptr(self.v), flat.numel(),
-                                                     _ptr(self._dev), _ptr(grad_scale), _stream(flat.device)),
+                                                     _ptr(self._dev), _ptr(grad_scale), int(divide), _stream(flat.device)),
                        "gcnn_adam_step_dev")
 
     def sync_from_device(self):
@@ -98,7 +99,6 @@ class TrainState:
         self.buf = torch.zeros(n + 4, dtype=torch.float32, device=model.device)
         self.grads = self.buf[:n]
         self.count = self.buf[n:n + 1]
-        self.inv_count = torch.ones(1, dtype=torch.float32, device=model.device)
 
 
 def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam | None, state: TrainState,
@@ -121,13 +121,12 @@ def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam
         return loss, scores
     import torch.distributed as dist
     loss, d_scores = mse_loss(scores, targets, 1.0)  # local SUM of squared errors
-    model._backward_into(flat, batch, ws, d_scores, state.grads)
+    model._backward_into(flat, batch, ws, d_scores, state.grads, count_slot=state.count)  # also stores the local cut count
     model._give_workspace(ws)
-    state.count.fill_(float(n_cuts))
-    dist.all_reduce(state.buf, op=dist.ReduceOp.SUM, group=process_group)
-    torch.reciprocal(state.count, out=state.inv_count)
-    if optimizer is not None:
-        (optimizer.apply_flat_dev if device_optimizer else optimizer.apply_flat)(model, state.grads, grad_scale=state.inv_count)
+    dist.all_reduce(state.buf, op=dist.ReduceOp.SUM, group=process_group)   # ONE collective: gradients + cut count
+    if optimizer is not None:  # Adam divides by the global cut count: the mean over ALL cuts of the global batch
+        (optimizer.apply_flat_dev if device_optimizer else optimizer.apply_flat)(model, state.grads, grad_scale=state.count,
+                                                                              divide=True)
     return loss, scores
 
 

@@ -128,7 +128,9 @@ int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float sc
  * gcnn_forward on the same workspace, inputs and parameters. */
 int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
-                  float* workspace, size_t workspace_floats, const float* d_scores, float* grads, void* stream);
+                  float* workspace, size_t workspace_floats, const float* d_scores, float* grads,
+                  float* cut_count_out /* optional: receives (float)n_cuts, the slot data-parallel callers all-reduce
+                                          together with the gradients */, void* stream);
 
 /* ---- PreNorm fitting statistics: PreNormLayer.update_params, model.py:394-423 -----------------------------------
  * For ONE batch and ONE of the 11 PreNorm layers (call order: 0 cons, 1 cons-edge, 2 var, 3 cut, 4 cut-edge, then
@@ -142,15 +144,16 @@ int gcnn_prenorm_stats(const gcnn_dims* dims, const float* params, const float* 
 
 /* ---- Keras-form Adam over the flat buffer: model_trainer.py:131,273 ------------------------------------------
  * theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (host double).
- * grad_scale (optional device scalar, may be NULL) multiplies every gradient first (data-parallel mean). */
+ * grad_scale (optional device scalar, may be NULL) multiplies every gradient first -- or divides it when
+ * scale_is_divisor != 0 (data parallel: the all-reduced global cut count). */
 int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1,
-                   float beta2, float eps, const float* grad_scale, void* stream);
+                   float beta2, float eps, const float* grad_scale, int32_t scale_is_divisor, void* stream);
 
 /* The same update with hyper-parameters and step counter on the device, so that a captured hipGraph of a whole training
  * step can be replayed: opt_state = {lr, beta1, beta2, eps, t, lr_t} (6 floats, device).  Each call advances t by one and
  * recomputes lr_t; the caller changes lr (the plateau schedule of model_trainer.py:177-179) by writing opt_state[0]. */
 int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
-                       const float* grad_scale, void* stream);
+                       const float* grad_scale, int32_t scale_is_divisor, void* stream);
 
 /* ---- ranking-prefix accuracy on the device: model_trainer.py:280-302 / model_tester.py:205-224 ----------------------
  * Per sample s (cuts offsets[s] .. offsets[s+1]-1 of the stacked vectors): rank by pred and by truth, descending, ties in

@@ -207,3 +207,30 @@ def test_device_ranking_metric_matches_reference_semantics(dev):
     np.testing.assert_allclose(frac.cpu().numpy(), want, rtol=1e-6)
     np.testing.assert_array_equal(acc.cpu().numpy(), (want[:, None] >= fractions[None, :]).sum(0))
     assert float(loss_acc) == 0.5 * n_cuts.sum()
+
+
+def test_dp_step_world1_equals_single_gpu_step(dev):
+    """The data-parallel branch (SUM loss, count slot stored by backward, Adam dividing by the reduced count) with the
+    collective replaced by the identity (world size 1) must update the weights exactly like the single-GPU branch."""
+    from gcnn_cut_selector_amd.trainer import Adam, TrainState, mse_loss
+    state, y, _ = synthetic.make_batch("indset", 2)
+    outs = []
+    for dp in (False, True):
+        m, _ = _model(40, dev)
+        batch = m.prepare(state)
+        yt = torch.as_tensor(y).to(dev)
+        opt, ts = Adam(1e-3), TrainState(m)
+        flat = m.flat_parameters.detach()
+        ws = m._take_workspace(batch)
+        scores = m._forward_into(flat, batch, ws)
+        if dp:
+            _, d = mse_loss(scores, yt, 1.0)
+            m._backward_into(flat, batch, ws, d, ts.grads, count_slot=ts.count)
+            assert float(ts.count) == batch.dims.n_cuts
+            opt.apply_flat(m, ts.grads, grad_scale=ts.count, divide=True)
+        else:
+            _, d = mse_loss(scores, yt)
+            m._backward_into(flat, batch, ws, d, ts.grads)
+            opt.apply_flat(m, ts.grads)
+        outs.append(m.flat_parameters.detach().cpu().numpy().copy())
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-7)
