@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch shi
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
 LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GcnnError(RuntimeError):
@@ -39,7 +39,8 @@ SIGNATURES = {
     "gcnn_param_total_floats": (C.c_int, []),
     "gcnn_param_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
     "gcnn_graph_temp_bytes": (_Z, [_I]),
-    "gcnn_graph_build": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "gcnn_graph_check": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "gcnn_graph_build": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "gcnn_seg_sum_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
     "gcnn_seg_bcast_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
     "gcnn_linear_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),

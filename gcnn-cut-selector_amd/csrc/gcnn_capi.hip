@@ -147,7 +147,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 2; }
+int gcnn_abi_version(void) { return 3; }
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -178,9 +178,22 @@ size_t gcnn_graph_temp_bytes(int32_t n_edges) {
     return sort_temp_bytes(n_edges) + 5 * e;  // cub temp + iota + sorted keys + two permutations + one inverse
 }
 
+// flags[0] != 0: an index is out of range; flags[1] != 0: the list is NOT sorted by left id (ties in any order)
+int gcnn_graph_check(const int32_t* edge_inds, int32_t n_edges, int32_t n_left, int32_t n_var, int32_t* flags,
+                     void* stream) {
+    if (n_edges < 0 || !flags || (n_edges > 0 && !edge_inds)) return GCNN_E_BADARG;
+    HIPCHK(hipMemsetAsync(flags, 0, 2 * sizeof(int), (hipStream_t)stream));
+    if (n_edges == 0) return 0;
+    hipLaunchKernelGGL(k_check_edges, dim3(std::min(cdiv(n_edges, 256), 1024)), dim3(256), 0, (hipStream_t)stream,
+                       edge_inds, n_edges, n_left, n_var, flags);
+    LAUNCHCHK();
+    return 0;
+}
+
 int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left, int32_t n_var,
-                     int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth, float* v_coef,
-                     int32_t* l2v, int32_t* v2l, int32_t* l_perm, void* temp, size_t temp_bytes, void* stream) {
+                     int32_t left_sorted, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
+                     float* v_coef, int32_t* l2v, int32_t* v2l, int32_t* l_perm, void* temp, size_t temp_bytes,
+                     void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_edges < 0 || n_left < 0 || n_var < 0 || !l_ptr || !v_ptr) return GCNN_E_BADARG;
     if (temp_bytes < gcnn_graph_temp_bytes(n_edges)) return GCNN_E_WORKSPACE;
@@ -206,6 +219,15 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
     for (int side = 0; side < 2; ++side) {
         const int* key_in = side == 0 ? left : var;
         const int nseg = side == 0 ? n_left : n_var;
+        if (side == 0 && left_sorted) {
+            // the reference emits (row, col)-sorted COO (utils.py:102-104): the by-left order is the input order
+            hipLaunchKernelGGL(k_seg_offsets, dim3(grid), dim3(256), 0, st, left, n_edges, nseg, l_ptr);
+            LAUNCHCHK();
+            HIPCHK(hipMemcpyAsync(l_oth, var, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(l_coef, edge_feats, (size_t)n_edges * sizeof(float), hipMemcpyDeviceToDevice, st));
+            perm[0] = iota;
+            continue;
+        }
         int bits = 1;
         while ((1ll << bits) < (long long)nseg + 1 && bits < 31) ++bits;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, keys, (const int*)iota, perm[side], n_edges,
@@ -218,12 +240,20 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
     }
     if (l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm[0], (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (v2l) {  // by-variable position -> by-left position of the same edge
-        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[0], n_edges, inv); LAUNCHCHK();
-        hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[1], inv, n_edges, v2l); LAUNCHCHK();
+        if (left_sorted) {
+            HIPCHK(hipMemcpyAsync(v2l, perm[1], (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+        } else {
+            hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[0], n_edges, inv); LAUNCHCHK();
+            hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[1], inv, n_edges, v2l); LAUNCHCHK();
+        }
     }
     if (l2v) {
         hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[1], n_edges, inv); LAUNCHCHK();
-        hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[0], inv, n_edges, l2v); LAUNCHCHK();
+        if (left_sorted) {
+            HIPCHK(hipMemcpyAsync(l2v, inv, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
+        } else {
+            hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[0], inv, n_edges, l2v); LAUNCHCHK();
+        }
     }
     return 0;
 }

@@ -240,6 +240,17 @@ __global__ void k_expand_ptr(const int* __restrict__ ptr, int n_seg, int* __rest
 // ---------------------------------------------------------------------------------------------------------------
 // graph plan kernels
 // ---------------------------------------------------------------------------------------------------------------
+// one pass over the COO list: flags[0] |= out-of-range index, flags[1] |= left ids not non-decreasing
+__global__ void k_check_edges(const int* __restrict__ ei, int n, int n_left, int n_var, int* __restrict__ flags) {
+    int bad = 0, unsorted = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int l = ei[i], v = ei[n + i];
+        bad |= (l < 0) | (l >= n_left) | (v < 0) | (v >= n_var);
+        if (i + 1 < n) unsorted |= ei[i + 1] < l;
+    }
+    if (bad) atomicOr(&flags[0], 1);
+    if (unsorted) atomicOr(&flags[1], 1);
+}
 __global__ void k_iota(int* p, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
 }

@@ -43,11 +43,17 @@ class BipartiteGraph:
         dev = edge_inds.device
         edge_inds = edge_inds.contiguous()
         edge_feats = edge_feats.contiguous()
-        if validate and n_edges > 0:
-            lo = int(edge_inds.min())
-            hi_l, hi_v = int(edge_inds[0].max()), int(edge_inds[1].max())
-            if lo < 0 or hi_l >= n_left or hi_v >= n_var:
-                raise ValueError(f"edge index out of range: min {lo}, max left {hi_l} (n={n_left}), max var {hi_v} (n={n_var})")
+        lib = _lib.lib()
+        left_sorted = 0
+        if validate and n_edges > 0:   # one kernel + one 8-byte read: range check and "already sorted by left id?"
+            flags = torch.empty(2, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.gcnn_graph_check(_ptr(edge_inds), n_edges, n_left, n_var, _ptr(flags), _stream(dev)),
+                           "gcnn_graph_check")
+            bad, unsorted = flags.tolist()
+            if bad:
+                raise ValueError(f"edge index out of range (left ids must be in [0,{n_left}), variable ids in [0,{n_var}))")
+            left_sorted = int(not unsorted)
         self.n_edges, self.n_left, self.n_var, self.device = n_edges, int(n_left), int(n_var), dev
         i32 = dict(dtype=torch.int32, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
@@ -60,11 +66,10 @@ class BipartiteGraph:
         self.l2v = torch.empty(n_edges, **i32)   # by-left position -> by-variable position of the same edge
         self.v2l = torch.empty(n_edges, **i32)
         self.l_perm = torch.empty(n_edges, **i32) if keep_perm else None
-        lib = _lib.lib()
         temp_bytes = lib.gcnn_graph_temp_bytes(n_edges)
         temp = torch.empty(temp_bytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.gcnn_graph_build(_ptr(edge_inds), _ptr(edge_feats), n_edges, n_left, n_var,
+            _lib.check(lib.gcnn_graph_build(_ptr(edge_inds), _ptr(edge_feats), n_edges, n_left, n_var, left_sorted,
                                             _ptr(self.l_ptr), _ptr(self.l_oth), _ptr(self.l_coef), _ptr(self.v_ptr),
                                             _ptr(self.v_oth), _ptr(self.v_coef), _ptr(self.l2v), _ptr(self.v2l),
                                             _ptr(self.l_perm), _ptr(temp),

@@ -150,6 +150,8 @@ class GCNN:
                                  ("float32", (None, 14)), ("float32", (None, 6)), ("int32", (2, None)),
                                  ("float32", (None, 1)), ("int32", ()), ("int32", ()), ("int32", ())), ("bool", ())]
         self._ws_pool = []
+        self._pin = None          # pinned host staging buffer for prepare()
+        self._pin_event = None
         self._prenorm_state = None
         self._init_weights(np.random.default_rng(seed))
 
@@ -231,6 +233,33 @@ class GCNN:
         self.set_weights(arrays)
 
     # ---- inputs ------------------------------------------------------------------------------------------------
+    def _stage_host_arrays(self, arrays):
+        """ONE host->device copy for all seven input arrays: pack them (16-byte aligned) into a pinned staging buffer,
+        copy once, and hand out typed views of the device buffer (which the views keep alive)."""
+        specs, total = [], 0
+        for a, dt in arrays:
+            a = np.ascontiguousarray(np.asarray(a), dtype=dt)
+            specs.append((a, total))
+            total += (a.nbytes + 15) & ~15
+        total = max(total, 16)
+        if self._pin is None or self._pin.numel() < total:
+            self._pin = torch.empty(max(total, 1 << 16), dtype=torch.uint8).pin_memory()
+            self._pin_event = None
+        if self._pin_event is not None:
+            self._pin_event.synchronize()      # the previous batch's copy must have left the staging buffer
+        host = self._pin.numpy()
+        for a, off in specs:
+            host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+        dev_buf = torch.empty(total, dtype=torch.uint8, device=self.device)
+        dev_buf.copy_(self._pin[:total], non_blocking=True)
+        self._pin_event = torch.cuda.Event()
+        self._pin_event.record(torch.cuda.current_stream(self.device))
+        out = []
+        for a, off in specs:
+            tdt = torch.float32 if a.dtype == np.float32 else torch.int32
+            out.append(dev_buf[off:off + a.nbytes].view(tdt).view(a.shape))
+        return out
+
     def prepare(self, inputs, validate=True) -> Batch:
         """10-tuple of NumPy arrays / torch tensors (model.py:263-275) -> device-resident Batch with CSR plans."""
         if isinstance(inputs, Batch):
@@ -239,9 +268,17 @@ class GCNN:
             raise ValueError(f"expected the reference's 10-tuple input, got {len(inputs)} items")
         c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts = inputs
         dev = self.device
-        c, v, k = (_as_device(x, torch.float32, dev) for x in (c, v, k))
-        cei, kei = _as_device(cei, torch.int32, dev), _as_device(kei, torch.int32, dev)
-        cef, kef = _as_device(cef, torch.float32, dev), _as_device(kef, torch.float32, dev)
+        if not any(isinstance(x, torch.Tensor) for x in (c, cei, cef, v, k, kei, kef)):
+            for name, x, kind in (("cons_edge_inds", cei, "iu"), ("cut_edge_inds", kei, "iu")):
+                if np.asarray(x).dtype.kind not in kind:
+                    raise ValueError(f"{name} must be an integer array, got {np.asarray(x).dtype}")
+            f32, i32 = np.float32, np.int32
+            c, cei, cef, v, k, kei, kef = self._stage_host_arrays(
+                [(c, f32), (cei, i32), (cef, f32), (v, f32), (k, f32), (kei, i32), (kef, f32)])
+        else:
+            c, v, k = (_as_device(x, torch.float32, dev) for x in (c, v, k))
+            cei, kei = _as_device(cei, torch.int32, dev), _as_device(kei, torch.int32, dev)
+            cef, kef = _as_device(cef, torch.float32, dev), _as_device(kef, torch.float32, dev)
         for name, t, f in (("cons_feats", c, 4), ("var_feats", v, 14), ("cut_feats", k, 6)):
             if t.dim() != 2 or t.shape[1] != f:
                 raise ValueError(f"{name} must have shape [N,{f}], got {tuple(t.shape)}")

@@ -56,8 +56,13 @@ typedef struct gcnn_graph {
  * edge_inds is the reference's [2,E] int32 tensor (row 0 = left id, row 1 = variable id, utils.py:110,234);
  * any edge order is accepted (stable sort => deterministic summation order). */
 size_t gcnn_graph_temp_bytes(int32_t n_edges);
+/* one pass over the list: flags[0] != 0 <=> some index is out of range; flags[1] != 0 <=> NOT sorted by left id */
+int gcnn_graph_check(const int32_t* edge_inds, int32_t n_edges, int32_t n_left, int32_t n_var, int32_t* flags,
+                     void* stream);
+/* left_sorted != 0 (as established by gcnn_graph_check; the reference's get_state emits (row, col)-sorted lists,
+ * utils.py:102-104) skips the by-left sort: the by-left order is then the input order. */
 int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left,
-                     int32_t n_var, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
+                     int32_t n_var, int32_t left_sorted, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
                      float* v_coef, int32_t* l2v /* optional */, int32_t* v2l /* optional */,
                      int32_t* l_perm /* optional [E]: by-left position -> input edge id */, void* temp, size_t temp_bytes,
                      void* stream);
