@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch shi
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
 LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GcnnError(RuntimeError):
@@ -29,6 +29,11 @@ class Graph(C.Structure):
                 ("l2v", C.c_void_p), ("v2l", C.c_void_p)]
 
 
+class CollateJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("unit_kind", C.c_int32), ("width", C.c_int32),
+                ("add_kind", C.c_int32), ("is_ptr", C.c_int32)]
+
+
 _P, _I, _F, _Z = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 _DP, _GP = C.POINTER(Dims), C.POINTER(Graph)
 
@@ -40,6 +45,7 @@ SIGNATURES = {
     "gcnn_param_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
     "gcnn_graph_temp_bytes": (_Z, [_I]),
     "gcnn_graph_check": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "gcnn_collate": (C.c_int, [_P, _I, _P, _P, _I, C.c_int64, _P]),
     "gcnn_graph_build": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "gcnn_seg_sum_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),
     "gcnn_seg_bcast_f32": (C.c_int, [_P, _P, _P, _I, _P, _P]),

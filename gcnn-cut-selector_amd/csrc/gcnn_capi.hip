@@ -147,7 +147,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 3; }
+int gcnn_abi_version(void) { return 4; }
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -176,6 +176,27 @@ static size_t sort_temp_bytes(int n) {
 size_t gcnn_graph_temp_bytes(int32_t n_edges) {
     const size_t e = ((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int) + 255) & ~(size_t)255;
     return sort_temp_bytes(n_edges) + 5 * e;  // cub temp + iota + sorted keys + two permutations + one inverse
+}
+
+// One launch gathers every array of a mini-batch out of a device-resident sample store (see k_collate)
+int gcnn_collate(const gcnn_collate_job* jobs, int32_t n_jobs, const int64_t* src_off, const int64_t* dst_off,
+                 int32_t batch, int64_t max_words, void* stream) {
+    if (n_jobs < 0 || n_jobs > COLLATE_MAX_JOBS || batch < 0 || max_words < 0) return GCNN_E_BADARG;
+    if (n_jobs == 0 || batch == 0) return 0;
+    if (!jobs || !src_off || !dst_off) return GCNN_E_BADARG;
+    CollateArgs a;
+    for (int i = 0; i < n_jobs; ++i) {
+        const gcnn_collate_job& j = jobs[i];
+        if (j.width < 1 || j.unit_kind < 0 || (j.is_ptr && (j.width != 1 || j.add_kind < 0))) return GCNN_E_BADARG;
+        a.job[i] = CollateJob{(const int*)j.src, (int*)j.dst, j.unit_kind, j.width, j.add_kind, j.is_ptr};
+    }
+    a.src_off = (const long long*)src_off;
+    a.dst_off = (const long long*)dst_off;
+    a.batch = batch;
+    const int bx = (int)std::min<int64_t>(std::max<int64_t>((max_words + 1 + 1023) / 1024, 1), 2048);
+    hipLaunchKernelGGL(k_collate, dim3(bx, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    LAUNCHCHK();
+    return 0;
 }
 
 // flags[0] != 0: an index is out of range; flags[1] != 0: the list is NOT sorted by left id (ties in any order)

@@ -238,6 +238,48 @@ __global__ void k_expand_ptr(const int* __restrict__ ptr, int n_seg, int* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// device-side batch collation: gather the samples of one mini-batch out of a device-resident sample store
+// (disjoint-union batching, utils.py:389-426).  Every store array keeps sample-local values; one launch copies all
+// arrays of the batch (blockIdx.y = array), shifting indices by the batch offset of the sample they land in.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int COLLATE_MAX_JOBS = 24;
+struct CollateJob {
+    const int* src;
+    int* dst;
+    int unit_kind, width, add_kind, is_ptr;
+};
+struct CollateArgs {
+    CollateJob job[COLLATE_MAX_JOBS];
+    const long long* src_off;   // [n_kinds][batch]   first unit of each chosen sample in the store
+    const long long* dst_off;   // [n_kinds][batch+1] first unit of each sample in the batch; last = batch total
+    int batch;
+};
+__global__ __launch_bounds__(256) void k_collate(CollateArgs a) {
+    const CollateJob j = a.job[blockIdx.y];
+    const long long* so = a.src_off + (size_t)j.unit_kind * a.batch;
+    const long long* dof = a.dst_off + (size_t)j.unit_kind * (a.batch + 1);
+    const long long* aof = j.add_kind >= 0 ? a.dst_off + (size_t)j.add_kind * (a.batch + 1) : nullptr;
+    const long long n_words = dof[a.batch] * j.width;
+    const long long n_out = n_words + (j.is_ptr ? 1 : 0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (long long)gridDim.x * blockDim.x) {
+        if (i == n_words) {   // trailing entry of a segment-offset array: the batch's edge total
+            j.dst[i] = (int)aof[a.batch];
+            continue;
+        }
+        const long long u = j.width == 1 ? i : i / j.width;
+        const int w = (int)(i - u * j.width);
+        int lo = 0, hi = a.batch;   // dof[lo] <= u < dof[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (dof[mid] <= u) lo = mid; else hi = mid;
+        }
+        int word = j.src[(so[lo] + (u - dof[lo])) * j.width + w];
+        if (aof) word += (int)aof[lo];
+        j.dst[i] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // graph plan kernels
 // ---------------------------------------------------------------------------------------------------------------
 // one pass over the COO list: flags[0] |= out-of-range index, flags[1] |= left ids not non-decreasing

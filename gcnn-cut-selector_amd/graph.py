@@ -76,6 +76,20 @@ class BipartiteGraph:
                                             temp_bytes, _stream(dev)), "gcnn_graph_build")
         # keep the temp alive until the stream has consumed it
         temp.record_stream(torch.cuda.current_stream(dev))
+        self._bind()
+
+    @classmethod
+    def from_plan(cls, n_left, n_var, l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef, l2v, v2l):
+        """Wrap CSR arrays that already exist on the device (SampleStore.batch collates them; no sort runs)."""
+        g = cls.__new__(cls)
+        g.n_edges, g.n_left, g.n_var, g.device = int(l_oth.numel()), int(n_left), int(n_var), l_ptr.device
+        g.l_ptr, g.l_oth, g.l_coef, g.v_ptr, g.v_oth, g.v_coef, g.l2v, g.v2l = l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef, l2v, v2l
+        g.l_perm = None
+        g._bind()
+        return g
+
+    def _bind(self):
+        n_edges = self.n_edges
         self.c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
                             self.l_coef.data_ptr() if n_edges else 0, self.v_ptr.data_ptr(),
                             self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0,

@@ -20,6 +20,7 @@ import torch
 from . import _lib
 from .graph import _ptr, _stream
 from .model import GCNN, Batch
+from .store import StoreBatch
 
 
 def mse_loss(scores: torch.Tensor, targets: torch.Tensor, scale: float | None = None, want_grad=True):
@@ -202,12 +203,15 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | No
     n_samples = cut_count = 0
     state = TrainState(model) if optimizer is not None else None
     for batch in dataloader:
-        (c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts, improvements) = batch
-        n_cuts = np.asarray(n_cuts).reshape(-1)
-        inputs = (c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)), int(n_cuts.sum()))
         try:
-            prepared = model.prepare(inputs)
-            y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(dev, non_blocking=True)
+            if isinstance(batch, StoreBatch):     # collated on the device by a SampleStore: nothing left to move
+                prepared, n_cuts, y = batch.batch, np.asarray(batch.n_cuts).reshape(-1), batch.improvements
+            else:
+                (c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts, improvements) = batch
+                n_cuts = np.asarray(n_cuts).reshape(-1)
+                prepared = model.prepare((c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)),
+                                          int(n_cuts.sum())))
+                y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(dev, non_blocking=True)
             if optimizer is not None:
                 loss, predictions = train_step(model, prepared, y, optimizer, state)
             else:
@@ -218,7 +222,7 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | No
             if len(n_cuts) and n_cuts.max() <= 4096:
                 ranking_metric(predictions.detach().as_subclass(torch.Tensor), y, n_cuts, frac_dev, acc_dev, loss, loss_dev)
             else:
-                pred, true = predictions.detach().cpu().numpy(), np.asarray(improvements)
+                pred, true = predictions.detach().cpu().numpy(), y.cpu().numpy()
                 start = 0
                 for nk in n_cuts:
                     host_acc += ranking_fraction(pred[start:start + nk], true[start:start + nk]) >= fractions
@@ -239,7 +243,10 @@ def pretrain(model: GCNN, dataloader):
     i = 0
     while True:
         for batch in dataloader:
-            inputs = tuple(batch[:7]) + (int(np.sum(batch[7])), int(np.sum(batch[8])), int(np.sum(batch[9])))
+            if isinstance(batch, StoreBatch):
+                inputs = batch.batch
+            else:
+                inputs = tuple(batch[:7]) + (int(np.sum(batch[7])), int(np.sum(batch[8])), int(np.sum(batch[9])))
             try:
                 if not model.pretrain(inputs, True):
                     break

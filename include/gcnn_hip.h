@@ -67,6 +67,24 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
                      int32_t* l_perm /* optional [E]: by-left position -> input edge id */, void* temp, size_t temp_bytes,
                      void* stream);
 
+/* ---- device-side batch collation: utils.load_batch's stacking (utils.py:389-426) on a device-resident sample store
+ * The store keeps every sample's arrays (features, targets and both CSR orders of both edge sets) concatenated in
+ * HBM with SAMPLE-LOCAL index values.  Because a mini-batch is a disjoint union, its arrays are the chosen samples'
+ * segments laid end to end with indices shifted by the sample's position in the batch (utils.py:401-407) -- CSR
+ * included, so no sort runs per batch.  One launch performs all copies.  A job copies `width` 4-byte words per unit
+ * (node row / edge / cut); units of sample-slot s go from src unit src_off[unit_kind][s].. to dst unit
+ * dst_off[unit_kind][s]..; int32 arrays add dst_off[add_kind][s] (add_kind < 0: plain copy); is_ptr arrays
+ * (segment offsets, width 1) get one trailing entry = dst_off[add_kind][batch].
+ * jobs: HOST array (<= 24); src_off [n_kinds][batch] and dst_off [n_kinds][batch+1]: DEVICE int64;
+ * max_words: the largest job's output size in words (sizes the grid). */
+typedef struct gcnn_collate_job {
+    const void* src;
+    void* dst;
+    int32_t unit_kind, width, add_kind, is_ptr;
+} gcnn_collate_job;
+int gcnn_collate(const gcnn_collate_job* jobs, int32_t n_jobs, const int64_t* src_off, const int64_t* dst_off,
+                 int32_t batch, int64_t max_words, void* stream);
+
 /* ---- standalone scatter-sum pass (K9): tf.scatter_nd(updates=[E,64], indices, shape=[R,64]), model.py:568-569
  * seg_ptr[R+1] are receiver-sorted segment offsets; perm (optional) maps sorted position -> row of `msg`
  * (NULL when msg is already receiver-sorted).  out[r] = sum of the segment's rows, 0 for empty segments. */
