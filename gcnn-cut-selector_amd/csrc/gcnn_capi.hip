@@ -411,42 +411,6 @@ static int launch_chain(const Chain& c, hipStream_t st) {
     return 0;
 }
 
-// ---- side streams ---------------------------------------------------------------------------------------------
-// The step is a chain of latency-bound launches that leave most of the chip idle, so independent work runs beside it on
-// two auxiliary HIP streams, forked from / joined back into the caller's stream with events (the pattern stream capture
-// turns into parallel graph branches): the three embedding chains in the forward pass; in the backward pass the weight
-// gradient jobs of each convolution (as soon as its edge pass has finished), the cut-/constraint-row tail chains and the
-// final reduction.  Results do not depend on the interleaving (no atomics).  GCNN_STREAMS=0 runs everything in order.
-struct Side { hipStream_t s[2]; hipEvent_t ev[16]; int next; int state; };  // state: 0 = not tried, 1 = on, -1 = off
-static Side g_side = {{nullptr, nullptr}, {}, 0, 0};
-static bool side_on() {
-    if (g_side.state == 0) {
-        const char* env = getenv("GCNN_STREAMS");
-        g_side.state = -1;
-        if (!(env && env[0] == '0')) {
-            bool ok = hipStreamCreateWithFlags(&g_side.s[0], hipStreamNonBlocking) == hipSuccess &&
-                      hipStreamCreateWithFlags(&g_side.s[1], hipStreamNonBlocking) == hipSuccess;
-            for (int i = 0; ok && i < 16; ++i) ok = hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) == hipSuccess;
-            if (ok) g_side.state = 1;
-        }
-    }
-    return g_side.state == 1;
-}
-// An event record costs the recording stream ~7 us on this platform, so fork points record ONCE and let every
-// dependent stream wait on the same event.
-static int ev_record(hipStream_t on, hipEvent_t* out) {
-    hipEvent_t e = g_side.ev[g_side.next];
-    g_side.next = (g_side.next + 1) & 15;
-    HIPCHK(hipEventRecord(e, on));
-    *out = e;
-    return 0;
-}
-static int ev_wait(hipStream_t st, hipEvent_t e, hipStream_t recorded_on) {
-    if (st == recorded_on) return 0;
-    HIPCHK(hipStreamWaitEvent(st, e, 0));
-    return 0;
-}
-
 // ---- forward ----------------------------------------------------------------------------------------------------
 struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-203, 294-296)
     int pbase;            // first parameter index of the block
@@ -520,18 +484,13 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     const bool save = save_for_backward != 0;
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
-    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496):
-    // three independent chains -> three streams
-    const bool side = side_on();
-    hipStream_t s1 = side ? g_side.s[0] : st, s2 = side ? g_side.s[1] : st;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (side && ((rc = ev_record(st, &e0)) || (rc = ev_wait(s1, e0, st)) || (rc = ev_wait(s2, e0, st)))) return rc;
+    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496)
     {
         Chain ch(d->n_cons);  // constraints: E1 -> Xc -> PL1
         ch.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); s.bias = p + poff(P_CONS + E_B2); s.relu = 1;
         ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); t.bias = p + poff(P_CONV0 + C_BL);
-        if ((rc = launch_chain(ch, s1))) return rc;
+        if ((rc = launch_chain(ch, st))) return rc;
     }
     {
         Chain ch(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
@@ -546,9 +505,8 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
         ch.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
         ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); s.bias = p + poff(P_CUT + E_B2); s.relu = 1;
         ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); t.bias = p + poff(P_CONV2 + C_BL);
-        if ((rc = launch_chain(ch, s2))) return rc;
+        if ((rc = launch_chain(ch, st))) return rc;
     }
-    if (side && ((rc = ev_record(s1, &e1)) || (rc = ev_record(s2, &e2)) || (rc = ev_wait(st, e1, s1)) || (rc = ev_wait(st, e2, s2)))) return rc;
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     if ((rc = conv_forward(p, cv[0], save, st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
@@ -586,7 +544,7 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
     if (gb) rd(src + EMB * EMB, gb, EMB);
     if (g2) rd(src + EMB * EMB + EMB, g2, EMB);
 }
-// launch the weight-gradient jobs collected so far as one grouped kernel on `st`; slabs keep accumulating
+// launch every collected weight-gradient job as ONE grouped kernel
 static int flush_wg(JobList& jl, hipStream_t st) {
     if (jl.wg.nblocks > 0) {
         hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(256), 0, st, jl.wg);
@@ -639,17 +597,6 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     return 0;
 }
 
-static int embed1_wgrad(int f, const float* x, const float* p, int pb, const float* dy, const float* yact, float* partial,
-                        int n, int nblk, hipStream_t st) {
-    if (n <= 0) return 0;
-    const float *sh = p + poff(pb + E_SHIFT), *sc = p + poff(pb + E_SCALE);
-    if (f == 4) hipLaunchKernelGGL(k_embed1_wgrad<4>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
-    else if (f == 14) hipLaunchKernelGGL(k_embed1_wgrad<14>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
-    else hipLaunchKernelGGL(k_embed1_wgrad<6>, dim3(nblk), dim3(256), 0, st, x, sh, sc, dy, yact, partial, n, EMB1_ROWS);
-    LAUNCHCHK();
-    return 0;
-}
-
 extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out, float* d_scores,
                   void* stream) {
     if (n < 0 || (n > 0 && (!scores || !targets))) return GCNN_E_BADARG;
@@ -676,10 +623,6 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     const Acts &A = w.a, &G = w.g;
     JobList jl; memset(&jl, 0, sizeof(jl)); jl.wg.partial = w.partial;
 
-    // side streams: sw runs the weight-gradient groups and the final reduction, sc the cut-/constraint-row tail chains
-    const bool side = side_on();
-    hipStream_t sw = side ? g_side.s[0] : st, sc = side ? g_side.s[1] : st;
-    hipEvent_t ev = nullptr, ev_sc = nullptr, ev_sw = nullptr;
     // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
     if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
@@ -690,15 +633,6 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
         {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
         {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
-    // first embedding layer's weight gradient (VALU) + the reduction jobs of its slab
-    auto embed_first_layer = [&](int i, hipStream_t s) -> int {
-        int r = embed1_wgrad(em[i].f, em[i].x, p, em[i].pb, em[i].ge1, em[i].e1, w.emb_partial[i], em[i].n, w.emb_nblk[i], s);
-        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
-        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
-        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
-        return r;
-    };
-
     // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
     hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
                        w.score_partial, cut_count_out, d->n_cuts);
@@ -713,13 +647,11 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[2], w, jl, st))) return rc;
-    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sc, ev, st)))) return rc;
-    if ((rc = flush_wg(jl, sw))) return rc;   // readout + conv v->k weight gradients
-    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k; then the cut embedding's first layer
+    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
         Chain ch(d->n_cuts);
         ChStage& s0 = ch.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); s0.add = G.Xk; s0.mask = A.Xk;
         ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
-        if ((rc = launch_chain(ch, sc)) || (rc = embed_first_layer(2, sc))) return rc;
+        if ((rc = launch_chain(ch, st))) return rc;
     }
     {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain
         Chain ch(d->n_vars);
@@ -728,8 +660,6 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
-    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)))) return rc;
-    if ((rc = flush_wg(jl, sw))) return rc;   // conv c->v weight gradients
     {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver chain
         Chain ch(d->n_cons);
         ChStage& s0 = ch.gemm(G.PL2, 0, p + poff(P_CONV1 + C_WL), 1, G.Xc2, 0); s0.mask = A.Xc2;
@@ -737,14 +667,11 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[0], w, jl, st))) return rc;
-    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sc, ev, st)))) return rc;
-    if ((rc = flush_wg(jl, sw))) return rc;   // conv v->c weight gradients
-    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c; then the constraint embedding's first layer
+    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
         Chain ch(d->n_cons);
         ChStage& s0 = ch.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); s0.add = G.Xc; s0.mask = A.Xc;
         ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
-        if ((rc = launch_chain(ch, sc)) || (rc = embed_first_layer(0, sc))) return rc;
-        if (side && (rc = ev_record(sc, &ev_sc))) return rc;
+        if ((rc = launch_chain(ch, st))) return rc;
     }
     {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v
         Chain ch(d->n_vars);
@@ -753,18 +680,34 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
         if ((rc = launch_chain(ch, st))) return rc;
     }
-    // tail on sw (needs all three tail chains): the embeddings' weight gradients, then the reduction of every slab
-    if (side && ((rc = ev_record(st, &ev)) || (rc = ev_wait(sw, ev, st)) || (rc = ev_wait(sw, ev_sc, sc)))) return rc;
-    if ((rc = embed_first_layer(1, sw))) return rc;
+    // Weight gradients: every operand pair now exists, so ALL of them go out as three grouped launches -- the first
+    // embedding layers (VALU, K = f <= 14), the 22 [64,64] products (MFMA), and the fixed-order reduction of the slabs.
+    // (Running them beside the critical path on side streams was slower: a cross-stream event edge costs 7-14 us here.)
+    {
+        Emb1Args ea; memset(&ea, 0, sizeof(ea)); ea.rows_per_block = EMB1_ROWS;
+        int nblk = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (em[i].n <= 0) continue;
+            ea.job[ea.njobs++] = Emb1Job{em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1,
+                                         w.emb_partial[i], em[i].n, em[i].f, nblk};
+            nblk += w.emb_nblk[i];
+            // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
+            add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
+            add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
+        }
+        if (nblk > 0) {
+            hipLaunchKernelGGL(k_embed1_wgrad, dim3(nblk), dim3(256), 0, st, ea);
+            LAUNCHCHK();
+        }
+    }
     for (int i = 0; i < 3; ++i)
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
-    if ((rc = flush_wg(jl, sw))) return rc;
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
+    if ((rc = flush_wg(jl, st))) return rc;
     if (jl.rdblk > 0) {
-        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, sw, jl.rd);
+        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
         LAUNCHCHK();
     }
-    if (side && ((rc = ev_record(sw, &ev_sw)) || (rc = ev_wait(st, ev_sw, sw)))) return rc;
     return 0;
 }
 

@@ -6,110 +6,134 @@
 // the forward chains (CH_EMBED1 in k_chain.hpp); here its weight gradient on the VALU (K = f <= 14).
 // ---------------------------------------------------------------------------------------------------------------
 // gradient of the first embedding layer's weights: dW[f][j] = sum_r xn[r][f] * dPre[r][j], db[j] = sum_r dPre[r][j]
-// with dPre = dY * (Y > 0).  One block per chunk of rows; per-block partial slab [(F+1)*64] (row F = bias).
+// with dPre = dY * (Y > 0).  One block per chunk of rows; per-block partial slab [(F+1)*64] (row F = bias).  The three
+// embeddings (F = 4, 14, 6) share one grouped launch: blockIdx picks the group.
+struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; };
+struct Emb1Args { int njobs; int rows_per_block; Emb1Job job[3]; };
+
 template <int F>
-__global__ __launch_bounds__(256) void k_embed1_wgrad(const float* __restrict__ x, const float* __restrict__ shift,
-                                                      const float* __restrict__ scale, const float* __restrict__ dy,
-                                                      const float* __restrict__ yact, float* __restrict__ partial,
-                                                      int n, int rows_per_block) {
-    __shared__ float red[4][(F + 1) * EMB];
+__device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int lb, int rows_per_block, float* red) {
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     float acc[F + 1];
 #pragma unroll
     for (int f = 0; f <= F; ++f) acc[f] = 0.f;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(n, r0 + rows_per_block);
+    const int r0 = lb * rows_per_block;
+    const int r1 = min(jb.n, r0 + rows_per_block);
 #pragma unroll 4
     for (int r = r0 + part; r < r1; r += 4) {
-        float d = dy[(size_t)r * EMB + col];
-        d = yact[(size_t)r * EMB + col] > 0.f ? d : 0.f;
+        float d = jb.dy[(size_t)r * EMB + col];
+        d = jb.yact[(size_t)r * EMB + col] > 0.f ? d : 0.f;
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] = fmaf((x[(size_t)r * F + f] + shift[f]) * scale[f], d, acc[f]);
+        for (int f = 0; f < F; ++f) acc[f] = fmaf((jb.x[(size_t)r * F + f] + jb.shift[f]) * jb.scale[f], d, acc[f]);
         acc[F] += d;
     }
 #pragma unroll
-    for (int f = 0; f <= F; ++f) red[part][f * EMB + col] = acc[f];
+    for (int f = 0; f <= F; ++f) red[part * 15 * EMB + f * EMB + col] = acc[f];
     __syncthreads();
     for (int i = threadIdx.x; i < (F + 1) * EMB; i += 256)
-        partial[(size_t)blockIdx.x * (F + 1) * EMB + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        jb.partial[(size_t)lb * (F + 1) * EMB + i] = (red[i] + red[15 * EMB + i]) + (red[2 * 15 * EMB + i] + red[3 * 15 * EMB + i]);
+}
+__global__ __launch_bounds__(256) void k_embed1_wgrad(Emb1Args a) {
+    __shared__ float red[4 * 15 * EMB];
+    int ji = 0;
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
+    const Emb1Job jb = a.job[ji];
+    const int lb = blockIdx.x - jb.blk0;
+    if (jb.f == 4) embed1_wgrad_body<4>(jb, lb, a.rows_per_block, red);
+    else if (jb.f == 6) embed1_wgrad_body<6>(jb, lb, a.rows_per_block, red);
+    else embed1_wgrad_body<14>(jb, lb, a.rows_per_block, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
 // Grouped launch: one job per (X, D) pair, one block per 256-row chunk of a job.  Wave w owns the 32x32 quadrant
-// (w>>1, w&1) of G; rows are the MFMA k dimension.  Per-block partial slab [64*64 + 64 + 64] floats; summed in a
-// fixed order by k_reduce (no atomics).
+// (w>>1, w&1) of G and never talks to the other waves: rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four
+// rows per instruction), and both operands come straight from global memory -- lane (m, g) loads the float2 at columns
+// 2m, 2m+1 of its quadrant's half of row 4*step+g, which serves two A (or B) variants, so one X load and one D load
+// feed four MFMAs.  No LDS, no barriers; loads run one 32-row batch ahead of the MFMAs.  Per-block partial slab
+// [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
 // ---------------------------------------------------------------------------------------------------------------
 #define WG_ROWS 256
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 24
+#define WG_STEPS 8   // 4-row MFMA steps per batch of loads
 struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float* d2; int n; int blk0; int slab0; };
 struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
 
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+struct WgBatch { float2 x[WG_STEPS], d[WG_STEPS], e[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
+
+// EXTRA: 0 = none, 1 = degree-weighted column sum (e.x = degree of the row), 2 = column sum of a second matrix (e = Q row)
+template <int EXTRA>
+__device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int xcol, int dcol) {
+#pragma unroll
+    for (int s = 0; s < WG_STEPS; ++s) {
+        const int r = row0 + 4 * s + g;
+        t.x[s] = t.d[s] = t.e[s] = make_float2(0.f, 0.f);
+        t.p0[s] = t.p1[s] = 0;
+        if (r < rend) {
+            t.x[s] = *(const float2*)(jb.x + (size_t)r * EMB + xcol);
+            t.d[s] = *(const float2*)(jb.d + (size_t)r * EMB + dcol);
+            if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
+            if (EXTRA == 2) t.e[s] = *(const float2*)(jb.d2 + (size_t)r * EMB + dcol);
+        }
+    }
+}
+
+template <int EXTRA>
+__device__ __forceinline__ void wg_body(const WgJob& jb, float* __restrict__ slab, int rbeg, int rend) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int qi = wv >> 1, qj = wv & 1, m = lane & 15, g = lane >> 4;
+    const int xcol = qi * 32 + 2 * m, dcol = qj * 32 + 2 * m;
+    f32x4w acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    float2 cs = make_float2(0.f, 0.f), ce = cs;
+    WgBatch cur, nxt;
+    wg_load<EXTRA>(cur, jb, rbeg, rend, g, xcol, dcol);
+    for (int row0 = rbeg; row0 < rend; row0 += 4 * WG_STEPS) {
+        wg_load<EXTRA>(nxt, jb, row0 + 4 * WG_STEPS, rend, g, xcol, dcol);   // past the chunk: all lanes load nothing
+#pragma unroll
+        for (int s = 0; s < WG_STEPS; ++s) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].x, cur.d[s].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].x, cur.d[s].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].y, cur.d[s].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].y, cur.d[s].y, acc[1][1], 0, 0, 0);
+            cs.x += cur.d[s].x; cs.y += cur.d[s].y;
+            if (EXTRA == 1) {
+                const float deg = (float)(cur.p1[s] - cur.p0[s]);
+                ce.x = fmaf(deg, cur.d[s].x, ce.x); ce.y = fmaf(deg, cur.d[s].y, ce.y);
+            }
+            if (EXTRA == 2) { ce.x += cur.e[s].x; ce.y += cur.e[s].y; }
+        }
+        cur = nxt;
+    }
+    const float sx = jb.sx ? *jb.sx : 1.f;
+    // acc[va][vb][t] = G[qi*32 + 2*(4g+t) + va][qj*32 + 2m + vb]
+#pragma unroll
+    for (int va = 0; va < 2; ++va)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            *(float2*)(slab + (qi * 32 + 2 * (4 * g + t) + va) * EMB + dcol) = make_float2(acc[va][0][t] * sx, acc[va][1][t] * sx);
+    // column sums: fold the four row slots (g) of the wave; the qi == 0 waves own them
+    cs.x += __shfl_xor(cs.x, 16); cs.y += __shfl_xor(cs.y, 16); ce.x += __shfl_xor(ce.x, 16); ce.y += __shfl_xor(ce.y, 16);
+    cs.x += __shfl_xor(cs.x, 32); cs.y += __shfl_xor(cs.y, 32); ce.x += __shfl_xor(ce.x, 32); ce.y += __shfl_xor(ce.y, 32);
+    if (qi == 0 && g == 0) {
+        *(float2*)(slab + EMB * EMB + dcol) = cs;
+        *(float2*)(slab + EMB * EMB + EMB + dcol) = ce;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) float xs[64 * LDW];
-    __shared__ __attribute__((aligned(16))) float ds[64 * LDW];
-    __shared__ float red[4][2 * EMB];
     int ji = 0;
     while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
     const WgJob jb = a.job[ji];
     const int lb = blockIdx.x - jb.blk0;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qi = wv >> 1, qj = wv & 1, i32 = lane & 31, h = lane >> 5;
-    const float sx = jb.sx ? *jb.sx : 1.f;
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float cs = 0.f, cds = 0.f;
     const int rbeg = lb * WG_ROWS, rend = min(jb.n, rbeg + WG_ROWS);
-    for (int row0 = rbeg; row0 < rend; row0 += 64) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // 64 rows x 16 float4 = 1024 float4 per matrix
-            const int idx = i * 256 + threadIdx.x;
-            const int r = idx >> 4, c = (idx & 15) * 4;
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
-            if (row0 + r < rend) {
-                xv = *(const float4*)(jb.x + (size_t)(row0 + r) * EMB + c);
-                dv = *(const float4*)(jb.d + (size_t)(row0 + r) * EMB + c);
-                xv.x *= sx; xv.y *= sx; xv.z *= sx; xv.w *= sx;
-            }
-            *(float4*)(xs + r * LDW + c) = xv;
-            *(float4*)(ds + r * LDW + c) = dv;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const int r = h * 32 + s;
-            acc = mfma32(xs[r * LDW + qi * 32 + i32], ds[r * LDW + qj * 32 + i32], acc);
-        }
-        // column sums of D (bias grads), 16 rows per thread
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int r = part * 16 + s;
-            const float dv = ds[r * LDW + col];
-            cs += dv;
-            const int gr = row0 + r;
-            if (jb.seg_ptr) {        // second column sum: degree-weighted (gradient of the hoisted b_f)
-                const float deg = gr < rend ? (float)(jb.seg_ptr[gr + 1] - jb.seg_ptr[gr]) : 0.f;
-                cds = fmaf(deg, dv, cds);
-            } else if (jb.d2) {      // ... or the plain column sum of a second matrix (Q -> d w_edge)
-                cds += gr < rend ? jb.d2[(size_t)gr * EMB + col] : 0.f;
-            }
-        }
-    }
     float* slab = a.partial + (size_t)(jb.slab0 + lb) * WG_SLAB;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        slab[(qi * 32 + row) * EMB + qj * 32 + i32] = acc[i];
-    }
-    red[part][col] = cs; red[part][EMB + col] = cds;
-    __syncthreads();
-    if (threadIdx.x < 2 * EMB)
-        slab[EMB * EMB + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (jb.seg_ptr) wg_body<1>(jb, slab, rbeg, rend);
+    else if (jb.d2) wg_body<2>(jb, slab, rbeg, rend);
+    else wg_body<0>(jb, slab, rbeg, rend);
 }
 
 // Fixed-order sum of partial slabs into the flat gradient buffer.  One block per (job, 64-float chunk).
