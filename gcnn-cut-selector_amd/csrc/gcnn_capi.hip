@@ -380,35 +380,63 @@ struct Chain {
     }
 };
 
-static int launch_chain(const Chain& c, hipStream_t st) {
-    const ChArgs& a = c.a;
-    if (a.n <= 0 || a.nstage == 0) return 0;
-    if (a.nstage > CH_MAX_STAGES || a.nw > CH_MAX_W) return GCNN_E_BADARG;
-    // every stage of a chain multiplies in the same direction; CH_EMBED1 / CH_SCORE only open / close forward chains
-    const bool transb = a.st[a.nstage - 1].type == CH_GEMM ? a.st[a.nstage - 1].transb != 0 : false;
-    for (int i = 0; i < a.nstage; ++i) {
-        if (a.st[i].type == CH_GEMM && (a.st[i].transb != 0) != transb) return GCNN_E_BADARG;
-        if (a.st[i].type == CH_EMBED1 && (i != 0 || transb)) return GCNN_E_BADARG;
-        if (a.st[i].type == CH_SCORE && (i != a.nstage - 1 || transb)) return GCNN_E_BADARG;
+// Launch up to CH_MAX_GROUPS independent chains (same multiplication direction) as one kernel.
+static int launch_chains(const Chain* const* chains, int n, hipStream_t st) {
+    ChMulti m; m.ngroups = 0; m.blk0[0] = 0;
+    int ntile[CH_MAX_GROUPS], total_tiles = 0, max_nw = 0;
+    bool transb = false;
+    for (int c = 0; c < n; ++c) {
+        const ChArgs& a = chains[c]->a;
+        if (a.n <= 0 || a.nstage == 0) continue;
+        if (m.ngroups >= CH_MAX_GROUPS || a.nstage > CH_MAX_STAGES || a.nw > CH_MAX_W) return GCNN_E_BADARG;
+        // every stage of every chain multiplies in the same direction; CH_EMBED1 / CH_SCORE only open / close forward chains
+        const bool tb = a.st[a.nstage - 1].type == CH_GEMM ? a.st[a.nstage - 1].transb != 0 : false;
+        if (m.ngroups > 0 && tb != transb) return GCNN_E_BADARG;
+        transb = tb;
+        for (int i = 0; i < a.nstage; ++i) {
+            if (a.st[i].type == CH_GEMM && (a.st[i].transb != 0) != transb) return GCNN_E_BADARG;
+            if (a.st[i].type == CH_EMBED1 && (i != 0 || transb)) return GCNN_E_BADARG;
+            if (a.st[i].type == CH_SCORE && (i != a.nstage - 1 || transb)) return GCNN_E_BADARG;
+        }
+        ntile[m.ngroups] = cdiv(a.n, 16);
+        total_tiles += ntile[m.ngroups];
+        max_nw = std::max(max_nw, a.nw);
+        m.g[m.ngroups++] = a;
     }
-    const int ntile = cdiv(a.n, 16);
+    if (m.ngroups == 0) return 0;
     // one block per CU (the staged weights fill most of the LDS); 8 waves per block once there is more than one tile
     // per wave so two waves share each SIMD's MFMA pipe and hide each other's loads
-    const bool big = ntile > 1024;
+    const bool big = total_tiles > 1024;
     const int nwaves = big ? 8 : 4;
-    const int smem = (a.nw * 64 * LDW + CH_MAX_STAGES * CH_PAR) * (int)sizeof(float);  // weights + per-stage parameters
-    const dim3 grid(std::min(cdiv(ntile, nwaves), 256)), block(nwaves * 64);
+    // blocks per group: one tile per wave when everything fits into 256 blocks, else 256 blocks split by work
+    int want[CH_MAX_GROUPS], sum_want = 0;
+    long long work[CH_MAX_GROUPS], sum_work = 0;
+    for (int i = 0; i < m.ngroups; ++i) {
+        want[i] = cdiv(ntile[i], nwaves); sum_want += want[i];
+        work[i] = (long long)ntile[i] * m.g[i].nstage; sum_work += work[i];
+    }
+    for (int i = 0; i < m.ngroups; ++i) {
+        int nb = want[i];
+        if (sum_want > 256) nb = std::max(1, std::min(want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
+        m.blk0[i + 1] = m.blk0[i] + nb;
+    }
+    const int smem = (max_nw * 64 * LDW + CH_MAX_STAGES * CH_PAR) * (int)sizeof(float);  // weights + per-stage parameters
+    const dim3 grid(m.blk0[m.ngroups]), block(nwaves * 64);
 #define CHAIN_CASE(NW, TB)                                                                                              \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_chain<NW, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
-        hipLaunchKernelGGL((k_chain<NW, TB>), grid, block, smem, st, a);                                                \
+        hipLaunchKernelGGL((k_chain<NW, TB>), grid, block, smem, st, m);                                                \
     } while (0)
     if (big) { if (transb) CHAIN_CASE(8, true); else CHAIN_CASE(8, false); }
     else { if (transb) CHAIN_CASE(4, true); else CHAIN_CASE(4, false); }
 #undef CHAIN_CASE
     LAUNCHCHK();
     return 0;
+}
+static int launch_chain(const Chain& c, hipStream_t st) {
+    const Chain* one[1] = {&c};
+    return launch_chains(one, 1, st);
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------
@@ -484,28 +512,24 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     const bool save = save_for_backward != 0;
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
-    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496)
+    // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496): three
+    // independent chains, one grouped launch
     {
-        Chain ch(d->n_cons);  // constraints: E1 -> Xc -> PL1
-        ch.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
-        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); s.bias = p + poff(P_CONS + E_B2); s.relu = 1;
-        ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); t.bias = p + poff(P_CONV0 + C_BL);
-        if ((rc = launch_chain(ch, st))) return rc;
-    }
-    {
-        Chain ch(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
-        ch.embed1(var_feats, 14, p, P_VAR, save ? A.E1v : nullptr);
-        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 0, A.Xv, 0); s.bias = p + poff(P_VAR + E_B2); s.relu = 1;
-        ch.gemm(nullptr, 0, p + poff(P_CONV0 + C_WR), 0, A.PR1, 1);
-        ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WR), 0, A.PR2, 1);
-        if ((rc = launch_chain(ch, st))) return rc;
-    }
-    {
-        Chain ch(d->n_cuts);  // cuts: E1 -> Xk -> PL3
-        ch.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
-        ChStage& s = ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); s.bias = p + poff(P_CUT + E_B2); s.relu = 1;
-        ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); t.bias = p + poff(P_CONV2 + C_BL);
-        if ((rc = launch_chain(ch, st))) return rc;
+        Chain cc(d->n_cons);  // constraints: E1 -> Xc -> PL1
+        cc.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
+        ChStage& sc = cc.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); sc.bias = p + poff(P_CONS + E_B2); sc.relu = 1;
+        ChStage& tc = cc.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); tc.bias = p + poff(P_CONV0 + C_BL);
+        Chain cv(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
+        cv.embed1(var_feats, 14, p, P_VAR, save ? A.E1v : nullptr);
+        ChStage& sv = cv.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 0, A.Xv, 0); sv.bias = p + poff(P_VAR + E_B2); sv.relu = 1;
+        cv.gemm(nullptr, 0, p + poff(P_CONV0 + C_WR), 0, A.PR1, 1);
+        cv.gemm(nullptr, 0, p + poff(P_CONV1 + C_WR), 0, A.PR2, 1);
+        Chain ck(d->n_cuts);  // cuts: E1 -> Xk -> PL3
+        ck.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
+        ChStage& sk = ck.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); sk.bias = p + poff(P_CUT + E_B2); sk.relu = 1;
+        ChStage& tk = ck.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); tk.bias = p + poff(P_CONV2 + C_BL);
+        const Chain* all[3] = {&cv, &cc, &ck};
+        if ((rc = launch_chains(all, 3, st))) return rc;
     }
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
@@ -647,17 +671,16 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[2], w, jl, st))) return rc;
-    {   // cut rows: dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
-        Chain ch(d->n_cuts);
-        ChStage& s0 = ch.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); s0.add = G.Xk; s0.mask = A.Xk;
-        ch.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
-        if ((rc = launch_chain(ch, st))) return rc;
-    }
-    {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain
-        Chain ch(d->n_vars);
-        ChStage& s0 = ch.gemm(G.PR3, 0, p + poff(P_CONV2 + C_WR), 1, G.Xv2, 0); s0.mask = A.Xv2;
-        conv_bwd_chain(ch, p, cv[1]);
-        if ((rc = launch_chain(ch, st))) return rc;
+    {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain; in the same launch the cut rows' tail:
+        // dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
+        Chain cv1(d->n_vars);
+        ChStage& s0 = cv1.gemm(G.PR3, 0, p + poff(P_CONV2 + C_WR), 1, G.Xv2, 0); s0.mask = A.Xv2;
+        conv_bwd_chain(cv1, p, cv[1]);
+        Chain ck(d->n_cuts);
+        ChStage& k0 = ck.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); k0.add = G.Xk; k0.mask = A.Xk;
+        ck.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
+        const Chain* both[2] = {&cv1, &ck};
+        if ((rc = launch_chains(both, 2, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
     {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver chain
@@ -667,18 +690,17 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_chain(ch, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[0], w, jl, st))) return rc;
-    {   // constraint rows: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
-        Chain ch(d->n_cons);
-        ChStage& s0 = ch.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); s0.add = G.Xc; s0.mask = A.Xc;
-        ch.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
-        if ((rc = launch_chain(ch, st))) return rc;
-    }
-    {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v
-        Chain ch(d->n_vars);
-        ChStage& s0 = ch.gemm(G.PR2, 0, p + poff(P_CONV1 + C_WR), 1, G.Xv, 0);
-        s0.in_b = G.PR1; s0.tb = 1; s0.wb = ch.weight(p + poff(P_CONV0 + C_WR)); s0.add = G.Xv; s0.mask = A.Xv;
-        ch.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
-        if ((rc = launch_chain(ch, st))) return rc;
+    {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v; in the same launch the
+        // constraint rows' tail: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
+        Chain cvf(d->n_vars);
+        ChStage& s0 = cvf.gemm(G.PR2, 0, p + poff(P_CONV1 + C_WR), 1, G.Xv, 0);
+        s0.in_b = G.PR1; s0.tb = 1; s0.wb = cvf.weight(p + poff(P_CONV0 + C_WR)); s0.add = G.Xv; s0.mask = A.Xv;
+        cvf.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
+        Chain ccf(d->n_cons);
+        ChStage& c0 = ccf.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); c0.add = G.Xc; c0.mask = A.Xc;
+        ccf.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
+        const Chain* both[2] = {&cvf, &ccf};
+        if ((rc = launch_chains(both, 2, st))) return rc;
     }
     // Weight gradients: every operand pair now exists, so ALL of them go out as three grouped launches -- the first
     // embedding layers (VALU, K = f <= 14), the 22 [64,64] products (MFMA), and the fixed-order reduction of the slabs.

@@ -34,6 +34,11 @@ struct ChStage {
     // CH_SCORE: out[r] = tile(ta)[r] . w1[0:64] + *bias
 };
 struct ChArgs { int n; int nstage; int nw; const float* w[CH_MAX_W]; ChStage st[CH_MAX_STAGES]; };
+// Independent chains over different row sets (the three embeddings; a tail chain beside a receiver chain) share ONE
+// launch: blocks [blk0[i], blk0[i+1]) run chain i.  Overlap without streams or events, one launch ramp instead of three.
+#define CH_MAX_GROUPS 3
+struct ChMulti { int ngroups; int blk0[CH_MAX_GROUPS + 1]; ChArgs g[CH_MAX_GROUPS]; };
+static_assert(sizeof(ChMulti) <= 4096, "kernel arguments are limited to 4 KB");
 
 // Register-resident chains.  Each stage computes the TRANSPOSED product  Y^T[64 x 16 rows] = Wop[64 x 64] . X^T  with the
 // weights as the MFMA A operand (read from LDS, independent of the data, so the reads run ahead) and the activation
@@ -97,12 +102,16 @@ __device__ __forceinline__ void rt_gemm(const RTile& t, float scale, const float
 
 #define CH_PAR 144  // per-stage LDS parameter block: bias[64], bd[64], {sa, so, es, score bias}, padding
 template <int NWAVES, bool TRANSB>
-__global__ __launch_bounds__(NWAVES * 64) void k_chain(ChArgs a) {
+__global__ __launch_bounds__(NWAVES * 64) void k_chain(ChMulti m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    int gi = 0;
+    while (gi + 1 < m.ngroups && (int)blockIdx.x >= m.blk0[gi + 1]) ++gi;
+    const ChArgs& a = m.g[gi];
+    const int bid = blockIdx.x - m.blk0[gi], nblk = m.blk0[gi + 1] - m.blk0[gi];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
-    const int tile0 = blockIdx.x * NWAVES + wv;
+    const int tile0 = bid * NWAVES + wv;
     float* par = smem + a.nw * 64 * LDW;
 
     // per-stage bias vectors and scalars go to LDS next to the weights (one dependent global read, once per block)
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_chain(ChArgs a) {
     }
     __syncthreads();
 
-    for (int tile = tile0; tile < ntile; tile += gridDim.x * NWAVES) {
+    for (int tile = tile0; tile < ntile; tile += nblk * NWAVES) {
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;   // the two register tiles stages read from / write to (ChStage.ta / tb / tout)
