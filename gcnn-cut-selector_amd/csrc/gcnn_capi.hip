@@ -1,5 +1,5 @@
 // gcnn_capi.hip -- C ABI (include/gcnn_hip.h) and host-side orchestration of the gfx950 (MI355X / CDNA4) kernels for the
-// bipartite GCNN hot path.  Kernels: k_chain.hpp (fused row chains), k_edge.hpp (edge passes, scatter-sum), k_wgrad.hpp
+// bipartite GCNN hot path.  Kernels: k_rows.hpp (fused row programs), k_edge.hpp (edge passes, scatter-sum), k_wgrad.hpp
 // (weight gradients), k_linear.hpp (standalone GEMM), k_misc.hpp (heads, Adam, PreNorm statistics, graph plan).
 //
 // Reference semantics (all cites into /root/reference): GCNN.call model.py:257-300, PartialGraphConvolution.call
@@ -14,7 +14,7 @@
 // reproducible results.
 
 #include "gcnn_common.hpp"
-#include "k_chain.hpp"
+#include "k_rows.hpp"
 #include "k_edge.hpp"
 #include "k_linear.hpp"
 #include "k_misc.hpp"
@@ -352,91 +352,71 @@ int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const fl
 
 }  // extern "C"
 
-// ---- fused row chains: host-side builders --------------------------------------------------------------------------
-struct Chain {
-    ChArgs a;
-    Chain(int n) { memset(&a, 0, sizeof(a)); a.n = n; }
-    int weight(const float* w) {  // returns the LDS slot of a 64x64 weight, staging each distinct matrix once
-        for (int i = 0; i < a.nw; ++i)
-            if (a.w[i] == w) return i;
-        a.w[a.nw] = w;
-        return a.nw++;
-    }
-    ChStage& gemm(const float* in_a, int ta, const float* w, int transb, float* out, int tout) {
-        ChStage& s = a.st[a.nstage++];
-        s.type = CH_GEMM; s.in_a = in_a; s.ta = ta; s.wa = weight(w); s.transb = transb; s.out = out; s.tout = tout;
-        return s;
-    }
-    ChStage& embed1(const float* x, int f, const float* p, int pb, float* out) {
-        ChStage& s = a.st[a.nstage++];
-        s.type = CH_EMBED1; s.x_raw = x; s.nfeat = f; s.shift = p + poff(pb + E_SHIFT); s.scale = p + poff(pb + E_SCALE);
-        s.w1 = p + poff(pb + E_W1); s.bias = p + poff(pb + E_B1); s.relu = 1; s.out = out; s.tout = 0;
-        return s;
-    }
-    ChStage& score(int ta, const float* w, const float* b, float* out) {
-        ChStage& s = a.st[a.nstage++];
-        s.type = CH_SCORE; s.ta = ta; s.w1 = w; s.bias = b; s.out = out;
-        return s;
-    }
-};
-
-// Launch up to CH_MAX_GROUPS independent chains (same multiplication direction) as one kernel.
-static int launch_chains(const Chain* const* chains, int n, hipStream_t st) {
-    ChMulti m; m.ngroups = 0; m.blk0[0] = 0;
-    int ntile[CH_MAX_GROUPS], total_tiles = 0, max_nw = 0;
-    bool transb = false;
-    for (int c = 0; c < n; ++c) {
-        const ChArgs& a = chains[c]->a;
-        if (a.n <= 0 || a.nstage == 0) continue;
-        if (m.ngroups >= CH_MAX_GROUPS || a.nstage > CH_MAX_STAGES || a.nw > CH_MAX_W) return GCNN_E_BADARG;
-        // every stage of every chain multiplies in the same direction; CH_EMBED1 / CH_SCORE only open / close forward chains
-        const bool tb = a.st[a.nstage - 1].type == CH_GEMM ? a.st[a.nstage - 1].transb != 0 : false;
-        if (m.ngroups > 0 && tb != transb) return GCNN_E_BADARG;
-        transb = tb;
-        for (int i = 0; i < a.nstage; ++i) {
-            if (a.st[i].type == CH_GEMM && (a.st[i].transb != 0) != transb) return GCNN_E_BADARG;
-            if (a.st[i].type == CH_EMBED1 && (i != 0 || transb)) return GCNN_E_BADARG;
-            if (a.st[i].type == CH_SCORE && (i != a.nstage - 1 || transb)) return GCNN_E_BADARG;
-        }
-        ntile[m.ngroups] = cdiv(a.n, 16);
-        total_tiles += ntile[m.ngroups];
-        max_nw = std::max(max_nw, a.nw);
-        m.g[m.ngroups++] = a;
-    }
-    if (m.ngroups == 0) return 0;
-    // one block per CU (the staged weights fill most of the LDS); 8 waves per block once there is more than one tile
-    // per wave so two waves share each SIMD's MFMA pipe and hide each other's loads
-    const bool big = total_tiles > 1024;
-    const int nwaves = big ? 8 : 4;
-    // blocks per group: one tile per wave when everything fits into 256 blocks, else 256 blocks split by work
-    int want[CH_MAX_GROUPS], sum_want = 0;
-    long long work[CH_MAX_GROUPS], sum_work = 0;
-    for (int i = 0; i < m.ngroups; ++i) {
+// ---- row programs: host-side launchers ---------------------------------------------------------------------------------
+// Blocks per program of a grouped launch.  One block per CU (the staged weights fill most of the LDS); 8 waves per block
+// once there is more than one tile per wave, so two waves share each SIMD's MFMA pipe and hide each other's loads.
+// One tile per wave when everything fits into 256 blocks, else 256 blocks split by work (tiles x stages).
+static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) {
+    int ntile[3], total = 0;
+    for (int i = 0; i < ngroups; ++i) { ntile[i] = n[i] > 0 ? cdiv(n[i], 16) : 0; total += ntile[i]; }
+    const int nwaves = total > 1024 ? 8 : 4;
+    int want[3], sum_want = 0;
+    long long work[3], sum_work = 0;
+    for (int i = 0; i < ngroups; ++i) {
         want[i] = cdiv(ntile[i], nwaves); sum_want += want[i];
-        work[i] = (long long)ntile[i] * m.g[i].nstage; sum_work += work[i];
+        work[i] = (long long)ntile[i] * nstage[i]; sum_work += work[i];
     }
-    for (int i = 0; i < m.ngroups; ++i) {
+    blk0[0] = 0;
+    for (int i = 0; i < ngroups; ++i) {
         int nb = want[i];
-        if (sum_want > 256) nb = std::max(1, std::min(want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
-        m.blk0[i + 1] = m.blk0[i] + nb;
+        if (sum_want > 256 && nb > 0) nb = std::max(1, std::min(want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
+        blk0[i + 1] = blk0[i] + nb;
     }
-    const int smem = (max_nw * 64 * LDW + CH_MAX_STAGES * CH_PAR) * (int)sizeof(float);  // weights + per-stage parameters
-    const dim3 grid(m.blk0[m.ngroups]), block(nwaves * 64);
-#define CHAIN_CASE(NW, TB)                                                                                              \
+    return nwaves;
+}
+#define ROWS_LAUNCH(KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ARGS)                                                     \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_chain<NW, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; } \
-        hipLaunchKernelGGL((k_chain<NW, TB>), grid, block, smem, st, m);                                                \
+        if (!attr_set) {                                                                                                \
+            HIPCHK(hipFuncSetAttribute((const void*)KERNEL8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+            HIPCHK(hipFuncSetAttribute((const void*)KERNEL4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        if ((NWAVES) == 8) hipLaunchKernelGGL(KERNEL8, dim3(GRID), dim3(512), SMEM, ST, ARGS);                          \
+        else hipLaunchKernelGGL(KERNEL4, dim3(GRID), dim3(256), SMEM, ST, ARGS);                                        \
+        LAUNCHCHK();                                                                                                    \
     } while (0)
-    if (big) { if (transb) CHAIN_CASE(8, true); else CHAIN_CASE(8, false); }
-    else { if (transb) CHAIN_CASE(4, true); else CHAIN_CASE(4, false); }
-#undef CHAIN_CASE
-    LAUNCHCHK();
+
+static int launch_embed_fwd(EmbGroupArgs& m, hipStream_t st) {
+    const int n[3] = {m.v.n, m.c.n, m.k.n}, ns[3] = {4, 3, 3};
+    const int nwaves = rows_blocks(n, ns, 3, m.blk0);
+    if (m.blk0[3] == 0) return 0;
+    ROWS_LAUNCH(k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3], EMB_LDS_FLOATS * sizeof(float), st, m);
     return 0;
 }
-static int launch_chain(const Chain& c, hipStream_t st) {
-    const Chain* one[1] = {&c};
-    return launch_chains(one, 1, st);
+static int launch_conv_fwd(const ConvFArgs& a, bool readout, hipStream_t st) {
+    int blk0[2];
+    const int ns = 4;
+    const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
+    if (blk0[1] == 0) return 0;
+    const size_t smem = ROWS_LDS_FLOATS(5, 5) * sizeof(float);
+    if (readout) ROWS_LAUNCH((k_conv_fwd<8, true>), (k_conv_fwd<4, true>), nwaves, blk0[1], smem, st, a);
+    else ROWS_LAUNCH((k_conv_fwd<8, false>), (k_conv_fwd<4, false>), nwaves, blk0[1], smem, st, a);
+    return 0;
+}
+static int launch_conv_bwd(ConvBGroupArgs& m, hipStream_t st) {
+    const int n[2] = {m.cb.n, m.tail.n}, ns[2] = {5, 2};
+    const int nwaves = rows_blocks(n, ns, 2, m.blk0);
+    if (m.blk0[2] == 0) return 0;
+    ROWS_LAUNCH(k_conv_bwd<8>, k_conv_bwd<4>, nwaves, m.blk0[2], ROWS_LDS_FLOATS(5, 1) * sizeof(float), st, m);
+    return 0;
+}
+static int launch_tail_bwd(TailGroupArgs& m, hipStream_t st) {
+    const int n[2] = {m.a.n, m.b.n}, ns[2] = {3, 2};
+    const int nwaves = rows_blocks(n, ns, 2, m.blk0);
+    if (m.blk0[2] == 0) return 0;
+    ROWS_LAUNCH(k_tail_bwd<8>, k_tail_bwd<4>, nwaves, m.blk0[2], ROWS_LDS_FLOATS(3, 1) * sizeof(float), st, m);
+    return 0;
 }
 
 // ---- forward ----------------------------------------------------------------------------------------------------
@@ -460,26 +440,24 @@ static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
     return e;
 }
 
-// edge pass + the receiver-side update chain S -> A -> Z1 -> X' (model.py:498-508, 568-573); `tail` appends the stages
-// that consume X' (the next convolution's projection or the readout) to the same launch
-template <class Tail>
-static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, Tail tail) {
+// edge pass + the receiver-side update program S -> A -> Z1 -> X' (model.py:498-508, 568-573) and, in the same launch, what
+// consumes X': the next convolution's projection (wt, bt -> t_out) or the readout
+static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, const float* wt, const float* bt,
+                        float* t_out, bool readout, float* scores) {
     int rc;
-    const int nr = c.recv_left ? c.nl : c.nv;
-    const float* xrecv = c.recv_left ? c.xl : c.xv;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
     e.out = c.S; e.mask = c.mask; e.cnt_rows = c.N;
     if ((rc = launch_edge_fwd(e, c.ne, save, st))) return rc;
-    Chain ch(nr);
-    ChStage& s0 = ch.gemm(c.S, 0, p + poff(c.pbase + C_WF), 0, save ? c.A : nullptr, 0);   // A = S Wf + deg*bf (K8 hoisted)
-    s0.bd = p + poff(c.pbase + C_BF); s0.seg_ptr = e.seg_ptr;
-    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 0, save ? c.Z1 : nullptr, 0);   // Z1 = relu([s2*A | x_recv] W1 + b1)
-    s1.sa = p + poff(c.pbase + C_S2); s1.in_b = xrecv; s1.tb = 1; s1.wb = ch.weight(p + poff(c.pbase + C_W1) + EMB * EMB);
-    s1.bias = p + poff(c.pbase + C_B1); s1.relu = 1;
-    ChStage& s2 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 0, c.OUT, 0);     // X' = relu(Z1 W2 + b2)
-    s2.bias = p + poff(c.pbase + C_B2); s2.relu = 1;
-    tail(ch);
-    return launch_chain(ch, st);
+    ConvFArgs a; memset(&a, 0, sizeof(a));
+    a.n = c.recv_left ? c.nl : c.nv;
+    a.s = c.S; a.seg_ptr = e.seg_ptr; a.wf = p + poff(c.pbase + C_WF); a.bf = p + poff(c.pbase + C_BF); a.a_out = save ? c.A : nullptr;
+    a.s2 = p + poff(c.pbase + C_S2); a.xrecv = c.recv_left ? c.xl : c.xv;
+    a.w1a = p + poff(c.pbase + C_W1); a.w1b = p + poff(c.pbase + C_W1) + EMB * EMB; a.b1 = p + poff(c.pbase + C_B1);
+    a.z1 = save ? c.Z1 : nullptr;
+    a.w2 = p + poff(c.pbase + C_W2); a.b2 = p + poff(c.pbase + C_B2); a.out = c.OUT;
+    a.wt = wt; a.bt = bt; a.t_out = t_out;
+    if (readout) { a.ws = p + poff(P_OUT + 2); a.bs = p + poff(P_OUT + 3); a.scores = scores; }
+    return launch_conv_fwd(a, readout, st);
 }
 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
@@ -513,36 +491,30 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
     // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496): three
-    // independent chains, one grouped launch
+    // independent programs, one grouped launch
     {
-        Chain cc(d->n_cons);  // constraints: E1 -> Xc -> PL1
-        cc.embed1(cons_feats, 4, p, P_CONS, save ? A.E1c : nullptr);
-        ChStage& sc = cc.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 0, A.Xc, 0); sc.bias = p + poff(P_CONS + E_B2); sc.relu = 1;
-        ChStage& tc = cc.gemm(nullptr, 0, p + poff(P_CONV0 + C_WL), 0, A.PL1, 1); tc.bias = p + poff(P_CONV0 + C_BL);
-        Chain cv(d->n_vars);  // variables: E1 -> Xv -> PR1, PR2 (both read the raw variable embedding, model.py:294-295)
-        cv.embed1(var_feats, 14, p, P_VAR, save ? A.E1v : nullptr);
-        ChStage& sv = cv.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 0, A.Xv, 0); sv.bias = p + poff(P_VAR + E_B2); sv.relu = 1;
-        cv.gemm(nullptr, 0, p + poff(P_CONV0 + C_WR), 0, A.PR1, 1);
-        cv.gemm(nullptr, 0, p + poff(P_CONV1 + C_WR), 0, A.PR2, 1);
-        Chain ck(d->n_cuts);  // cuts: E1 -> Xk -> PL3
-        ck.embed1(cut_feats, 6, p, P_CUT, save ? A.E1k : nullptr);
-        ChStage& sk = ck.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 0, A.Xk, 0); sk.bias = p + poff(P_CUT + E_B2); sk.relu = 1;
-        ChStage& tk = ck.gemm(nullptr, 0, p + poff(P_CONV2 + C_WL), 0, A.PL3, 1); tk.bias = p + poff(P_CONV2 + C_BL);
-        const Chain* all[3] = {&cv, &cc, &ck};
-        if ((rc = launch_chains(all, 3, st))) return rc;
+        EmbGroupArgs m; memset(&m, 0, sizeof(m));
+        auto emb = [&](EmbArgs& e, const float* x, int pb, float* e1, float* xo, int n) {
+            e.x = x; e.shift = p + poff(pb + E_SHIFT); e.scale = p + poff(pb + E_SCALE); e.w1 = p + poff(pb + E_W1);
+            e.b1 = p + poff(pb + E_B1); e.e1 = save ? e1 : nullptr; e.w2 = p + poff(pb + E_W2); e.b2 = p + poff(pb + E_B2);
+            e.xo = xo; e.n = n;
+        };
+        emb(m.v, var_feats, P_VAR, A.E1v, A.Xv, d->n_vars);    // variables: E1 -> Xv -> PR1, PR2 (model.py:294-295)
+        m.v.wp[0] = p + poff(P_CONV0 + C_WR); m.v.po[0] = A.PR1; m.v.wp[1] = p + poff(P_CONV1 + C_WR); m.v.po[1] = A.PR2;
+        emb(m.c, cons_feats, P_CONS, A.E1c, A.Xc, d->n_cons);  // constraints: E1 -> Xc -> PL1
+        m.c.wp[0] = p + poff(P_CONV0 + C_WL); m.c.bp[0] = p + poff(P_CONV0 + C_BL); m.c.po[0] = A.PL1;
+        emb(m.k, cut_feats, P_CUT, A.E1k, A.Xk, d->n_cuts);    // cuts: E1 -> Xk -> PL3
+        m.k.wp[0] = p + poff(P_CONV2 + C_WL); m.k.bp[0] = p + poff(P_CONV2 + C_BL); m.k.po[0] = A.PL3;
+        if ((rc = launch_embed_fwd(m, st))) return rc;
     }
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
-    if ((rc = conv_forward(p, cv[0], save, st, [&](Chain& ch) {   // updated constraints -> left projection of conv c->v
-            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_CONV1 + C_WL), 0, A.PL2, 1); t.bias = p + poff(P_CONV1 + C_BL);
-        }))) return rc;
-    if ((rc = conv_forward(p, cv[1], save, st, [&](Chain& ch) {   // updated variables -> right projection of conv v->k
-            ch.gemm(nullptr, 0, p + poff(P_CONV2 + C_WR), 0, A.PR3, 1);
-        }))) return rc;
-    if ((rc = conv_forward(p, cv[2], save, st, [&](Chain& ch) {   // updated cuts -> readout (model.py:206-208, 299-300)
-            ChStage& t = ch.gemm(nullptr, 0, p + poff(P_OUT), 0, save ? A.O1 : nullptr, 0); t.bias = p + poff(P_OUT + 1); t.relu = 1;
-            ch.score(0, p + poff(P_OUT + 2), p + poff(P_OUT + 3), scores);
-        }))) return rc;
+    // updated constraints -> left projection of conv c->v
+    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, false, nullptr))) return rc;
+    // updated variables -> right projection of conv v->k
+    if ((rc = conv_forward(p, cv[1], save, st, p + poff(P_CONV2 + C_WR), nullptr, A.PR3, false, nullptr))) return rc;
+    // updated cuts -> readout (model.py:206-208, 299-300)
+    if ((rc = conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), save ? A.O1 : nullptr, true, scores))) return rc;
     return 0;
 }
 
@@ -584,17 +556,18 @@ static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int st
     jl.rdblk += cdiv(len, EMB);
 }
 
-// Receiver-side gradient chain of one convolution, appended to `ch` whose tile 0 already holds dX' (masked):
-//   dZ1 = dX'pre W2^T (mask Z1) ; d x_recv = dZ1pre W1b^T ; dA = s2 * dZ1pre W1a^T ; dS = dA Wf^T
-static void conv_bwd_chain(Chain& ch, const float* p, const ConvIO& c) {
-    float* gxrecv = c.recv_left ? c.gXL : c.gXV;
-    ChStage& s1 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W2), 1, c.gZ1, 0); s1.mask = c.Z1;
-    ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1) + EMB * EMB, 1, gxrecv, 1);
-    ChStage& s3 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_W1), 1, c.gA, 0); s3.so = p + poff(c.pbase + C_S2);
-    // dS = dA Wf^T, and element-wise from it the receiver-ordered half of the edge gradient (see k_edge_fwd):
-    //   dP_recv = s1*dS*N
-    ChStage& s4 = ch.gemm(nullptr, 0, p + poff(c.pbase + C_WF), 1, c.gS, 0);
-    s4.em_s = p + poff(c.pbase + C_S1); s4.em_a = c.N; s4.em_out = c.recv_left ? c.gPL : c.gPR;
+// Receiver-side gradient program of one convolution, entered through the layer (w0) that consumed its output:
+// `in` is that layer's output gradient
+static ConvBArgs conv_bwd_args(const float* p, const ConvIO& c, const float* in, const float* w0) {
+    ConvBArgs a; memset(&a, 0, sizeof(a));
+    a.n = c.recv_left ? c.nl : c.nv;
+    a.in = in; a.w0 = w0; a.x_out = c.OUT; a.g_out = c.gOUT;
+    a.w2 = p + poff(c.pbase + C_W2); a.z1 = c.Z1; a.g_z1 = c.gZ1;
+    a.w1b = p + poff(c.pbase + C_W1) + EMB * EMB; a.g_xrecv = c.recv_left ? c.gXL : c.gXV;
+    a.w1a = p + poff(c.pbase + C_W1); a.s2 = p + poff(c.pbase + C_S2); a.g_a = c.gA;
+    a.wf = p + poff(c.pbase + C_WF); a.g_s = c.gS;
+    a.s1 = p + poff(c.pbase + C_S1); a.nrows = c.N; a.g_precv = c.recv_left ? c.gPL : c.gPR;
+    return a;
 }
 
 // sender-ordered half of the edge gradient, and the weight-gradient jobs of the whole convolution
@@ -664,43 +637,37 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), w.score_nblk, 2 * EMB, EMB);
     add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), w.score_nblk, 2 * EMB, 1);
     add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
-    {   // cut rows: readout -> conv v->k receiver chain
-        Chain ch(d->n_cuts);
-        ChStage& s0 = ch.gemm(G.O1, 0, p + poff(P_OUT), 1, G.Xk2, 0); s0.mask = A.Xk2;
-        conv_bwd_chain(ch, p, cv[2]);
-        if ((rc = launch_chain(ch, st))) return rc;
+    auto tail = [&](TailBArgs& t, const float* in_a, const float* wa, const float* in_b, const float* wb, float* gx, const float* x,
+                    int pb, float* ge1, int n) {
+        t.in_a = in_a; t.wa = wa; t.in_b = in_b; t.wb = wb; t.add = gx; t.x = x; t.g_x = gx; t.w2 = p + poff(pb + E_W2);
+        t.g_e1 = ge1; t.n = n;
+    };
+    {   // cut rows: readout -> conv v->k receiver gradients
+        ConvBGroupArgs m; memset(&m, 0, sizeof(m));
+        m.cb = conv_bwd_args(p, cv[2], G.O1, p + poff(P_OUT));
+        if ((rc = launch_conv_bwd(m, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[2], w, jl, st))) return rc;
-    {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver chain; in the same launch the cut rows' tail:
+    {   // variable rows: dXv2 = dPR3 Wr3^T (mask Xv2) -> conv c->v receiver gradients; in the same launch the cut rows' tail:
         // dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
-        Chain cv1(d->n_vars);
-        ChStage& s0 = cv1.gemm(G.PR3, 0, p + poff(P_CONV2 + C_WR), 1, G.Xv2, 0); s0.mask = A.Xv2;
-        conv_bwd_chain(cv1, p, cv[1]);
-        Chain ck(d->n_cuts);
-        ChStage& k0 = ck.gemm(G.PL3, 0, p + poff(P_CONV2 + C_WL), 1, G.Xk, 0); k0.add = G.Xk; k0.mask = A.Xk;
-        ck.gemm(nullptr, 0, p + poff(P_CUT + E_W2), 1, G.E1k, 0);
-        const Chain* both[2] = {&cv1, &ck};
-        if ((rc = launch_chains(both, 2, st))) return rc;
+        ConvBGroupArgs m; memset(&m, 0, sizeof(m));
+        m.cb = conv_bwd_args(p, cv[1], G.PR3, p + poff(P_CONV2 + C_WR));
+        tail(m.tail, G.PL3, p + poff(P_CONV2 + C_WL), nullptr, nullptr, G.Xk, A.Xk, P_CUT, G.E1k, d->n_cuts);
+        if ((rc = launch_conv_bwd(m, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
-    {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver chain
-        Chain ch(d->n_cons);
-        ChStage& s0 = ch.gemm(G.PL2, 0, p + poff(P_CONV1 + C_WL), 1, G.Xc2, 0); s0.mask = A.Xc2;
-        conv_bwd_chain(ch, p, cv[0]);
-        if ((rc = launch_chain(ch, st))) return rc;
+    {   // constraint rows: dXc2 = dPL2 Wl2^T (mask Xc2) -> conv v->c receiver gradients
+        ConvBGroupArgs m; memset(&m, 0, sizeof(m));
+        m.cb = conv_bwd_args(p, cv[0], G.PL2, p + poff(P_CONV1 + C_WL));
+        if ((rc = launch_conv_bwd(m, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[0], w, jl, st))) return rc;
     {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v; in the same launch the
         // constraint rows' tail: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
-        Chain cvf(d->n_vars);
-        ChStage& s0 = cvf.gemm(G.PR2, 0, p + poff(P_CONV1 + C_WR), 1, G.Xv, 0);
-        s0.in_b = G.PR1; s0.tb = 1; s0.wb = cvf.weight(p + poff(P_CONV0 + C_WR)); s0.add = G.Xv; s0.mask = A.Xv;
-        cvf.gemm(nullptr, 0, p + poff(P_VAR + E_W2), 1, G.E1v, 0);
-        Chain ccf(d->n_cons);
-        ChStage& c0 = ccf.gemm(G.PL1, 0, p + poff(P_CONV0 + C_WL), 1, G.Xc, 0); c0.add = G.Xc; c0.mask = A.Xc;
-        ccf.gemm(nullptr, 0, p + poff(P_CONS + E_W2), 1, G.E1c, 0);
-        const Chain* both[2] = {&cvf, &ccf};
-        if ((rc = launch_chains(both, 2, st))) return rc;
+        TailGroupArgs m; memset(&m, 0, sizeof(m));
+        tail(m.a, G.PR2, p + poff(P_CONV1 + C_WR), G.PR1, p + poff(P_CONV0 + C_WR), G.Xv, A.Xv, P_VAR, G.E1v, d->n_vars);
+        tail(m.b, G.PL1, p + poff(P_CONV0 + C_WL), nullptr, nullptr, G.Xc, A.Xc, P_CONS, G.E1c, d->n_cons);
+        if ((rc = launch_tail_bwd(m, st))) return rc;
     }
     // Weight gradients: every operand pair now exists, so ALL of them go out as three grouped launches -- the first
     // embedding layers (VALU, K = f <= 14), the 22 [64,64] products (MFMA), and the fixed-order reduction of the slabs.

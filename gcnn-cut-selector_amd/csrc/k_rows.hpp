@@ -1,0 +1,481 @@
+#pragma once
+#include "gcnn_common.hpp"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row programs.  Every node-side layer of the model is row-local: a 16-row tile of a [N,64] matrix goes through a
+// sequence of 64x64 products with element-wise epilogues.  Each such sequence -- an embedding with the projections it
+// feeds (model.py:174-198, 486-496), the receiver-side update S -> A -> Z1 -> X' -> next projection of a
+// PartialGraphConvolution (model.py:498-508, 570-573), or the gradient of either -- is ONE statically typed program:
+// a wave owns a tile, reads every weight from LDS (staged once per block), issues ALL global operand loads of the tile
+// before its first MFMA (one memory round trip per tile, whatever the number of stages) and stores only the tensors the
+// backward pass / the next edge pass need.  Independent programs over different row sets share a launch (block ranges).
+//
+// Register-resident transposed products.  Each stage computes  Y^T[64 x 16 rows] = Wop[64 x 64] . X^T  with the weights as
+// the MFMA A operand (v_mfma_f32_16x16x4_f32; read from LDS, independent of the data, so the reads run ahead) and the
+// activation tile as the B operand.  With that orientation the accumulator of one stage IS the B operand of the next:
+//   lane (j = lane&15, g = lane>>4) holds, for each 16-feature block m and i = 0..3, the element X[row0 + j][16*m + 4*g + i]
+//   -- as B operand of k-step (m, i) (the instruction's k index is g), and as C/D layout of output block m (rows of D =
+//   features 4*g + i of block m, column = row j of the tile).
+// So a whole program runs without any LDS round trip for activations; global rows are read/written as float4 pieces
+// X[row][16*m + 4*g .. +3] straight from/to that layout.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct RTile { float v[4][4]; };
+
+// Weights and bias vectors in LDS do not change from tile to tile, so the optimiser would hoist their reads out of the
+// tile loop -- 64 VGPRs per matrix, i.e. spills.  Adding an opaque zero to the address keeps each read where it is used.
+__device__ __forceinline__ const float* lds_here(const float* p) {
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    return p + zero;
+}
+
+__device__ __forceinline__ void rt_zero(RTile& t) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.v[m][i] = 0.f;
+}
+__device__ __forceinline__ void rt_load(RTile& t, const float* x, int row, bool ok, int g) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) f = *(const float4*)(x + (size_t)row * EMB + 16 * m + 4 * g);
+        t.v[m][0] = f.x; t.v[m][1] = f.y; t.v[m][2] = f.z; t.v[m][3] = f.w;
+    }
+}
+__device__ __forceinline__ void rt_store(const RTile& t, float* x, int row, bool ok, int g) {
+    if (!ok || !x) return;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        *(float4*)(x + (size_t)row * EMB + 16 * m + 4 * g) = make_float4(t.v[m][0], t.v[m][1], t.v[m][2], t.v[m][3]);
+}
+
+// acc[mo] += Wop[16*mo + (lane&15)][kf] * (scale * T[kf]), kf = 16*mt + 4*g + i;
+// forward (x @ W): Wop[o][k] = W[k][o];  backward (x @ W^T): Wop[o][k] = W[o][k].  wl: the matrix in LDS, row stride LDW.
+template <bool TRANSB>
+__device__ __forceinline__ void rt_gemm(const RTile& t, float scale, const float* wl, f32x4 (&acc)[4], int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    wl = lds_here(wl);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        float av[4][4];  // [mo][i]
+        if (TRANSB) {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) {
+                const float4 w4 = *(const float4*)(wl + (16 * mo + m) * LDW + 16 * mt + 4 * g);
+                av[mo][0] = w4.x; av[mo][1] = w4.y; av[mo][2] = w4.z; av[mo][3] = w4.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mo = 0; mo < 4; ++mo) av[mo][i] = wl[(16 * mt + 4 * g + i) * LDW + 16 * mo + m];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float b = t.v[mt][i] * scale;
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) acc[mo] = mfma16(av[mo][i], b, acc[mo]);
+        }
+    }
+}
+// o = (scale * in) x W
+template <bool TRANSB>
+__device__ __forceinline__ void rt_mm(RTile& o, const RTile& in, float scale, const float* wl, int lane) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) acc[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rt_gemm<TRANSB>(in, scale, wl, acc, lane);
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[mo][i] = acc[mo][i];
+}
+// o = (sa * a) x Wa + b x Wb   (same accumulators, a first)
+template <bool TRANSB>
+__device__ __forceinline__ void rt_mm2(RTile& o, const RTile& a, float sa, const float* wa, const RTile& b, const float* wb, int lane) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo) acc[mo] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rt_gemm<TRANSB>(a, sa, wa, acc, lane);
+    rt_gemm<TRANSB>(b, 1.f, wb, acc, lane);
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[mo][i] = acc[mo][i];
+}
+// o += vec (a [64] vector in LDS), then optional ReLU
+template <bool RELU>
+__device__ __forceinline__ void rt_bias(RTile& o, const float* vec, int g) {
+    vec = lds_here(vec);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4 b = *(const float4*)(vec + 16 * m + 4 * g);
+        const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = o.v[m][i] + bv[i];
+            o.v[m][i] = RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+__device__ __forceinline__ void rt_mask(RTile& o, const RTile& act) {   // o *= (act > 0): gradient of a ReLU whose output is act
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[m][i] = act.v[m][i] > 0.f ? o.v[m][i] : 0.f;
+}
+__device__ __forceinline__ void rt_clear_unless(RTile& o, bool ok) {    // rows past the end of the matrix stay exactly zero
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[m][i] = ok ? o.v[m][i] : 0.f;
+}
+
+// Stage NM 64x64 matrices ([64][LDW] each) and NV 64-float vectors (nullptr -> zeros) into LDS: every global load is
+// issued before the first LDS write, so a block pays ONE round trip for all of them.
+template <int NM, int NV, int NT>
+__device__ __forceinline__ void stage_lds(float* smem, const float* const (&w)[NM], const float* const (&v)[NV]) {
+    constexpr int PER = 1024 / NT;   // float4 per thread per matrix: 4 (256 threads) or 2 (512)
+    float4 tmp[NM][PER];
+    float vec[NV];
+#pragma unroll
+    for (int wi = 0; wi < NM; ++wi)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tmp[wi][i] = *(const float4*)(w[wi] + (size_t)(i * NT + threadIdx.x) * 4);
+#pragma unroll
+    for (int vi = 0; vi < NV; ++vi) vec[vi] = (threadIdx.x < 64 && v[vi]) ? v[vi][threadIdx.x] : 0.f;
+#pragma unroll
+    for (int wi = 0; wi < NM; ++wi)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NT + threadIdx.x;
+            *(float4*)(smem + wi * 64 * LDW + (idx >> 4) * LDW + (idx & 15) * 4) = tmp[wi][i];
+        }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int vi = 0; vi < NV; ++vi) smem[NM * 64 * LDW + vi * 64 + threadIdx.x] = vec[vi];
+    }
+}
+#define ROWS_LDS_FLOATS(NM, NV) ((NM) * 64 * LDW + (NV) * 64)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Program 1 (forward): embedding + the projections of the raw embedding (model.py:174-198 applied :287-291; :486-496)
+//   E1 = relu(((x + shift) * scale) W1 + b1)   [VALU, K = F <= 14]      -> e1 (optional: kept for the backward pass)
+//   X  = relu(E1 W2 + b2)                                               -> xo
+//   P_k = X Wp_k (+ bp_k)                        k < NPROJ               -> po[k]
+// ---------------------------------------------------------------------------------------------------------------
+struct EmbArgs {
+    const float *x, *shift, *scale, *w1, *b1; float* e1;
+    const float *w2, *b2; float* xo;
+    const float* wp[2]; const float* bp[2]; float* po[2];
+    int n;
+};
+template <int F, int NPROJ, int NT>
+__device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int bid, int nblk) {
+    constexpr int NWAVES = NT / 64, NM = 1 + NPROJ, NV = 2 + NPROJ;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int ntile = (a.n + 15) >> 4;
+    float* vecs = smem + NM * 64 * LDW;
+    float* w1s = smem + ROWS_LDS_FLOATS(NM, NV);   // first-layer kernel [F][64], bias b1 in vecs[0]
+    int tile = bid * NWAVES + wv;
+    float xv[F];
+    auto load_ops = [&](int t) {
+        const int row = t * 16 + j;
+#pragma unroll
+        for (int f = 0; f < F; ++f) xv[f] = row < a.n ? a.x[(size_t)row * F + f] : 0.f;
+    };
+    load_ops(tile);
+    if (NPROJ == 2) {
+        const float* const w[3] = {a.w2, a.wp[0], a.wp[1]};
+        const float* const v[4] = {a.b1, a.b2, a.bp[0], a.bp[1]};
+        stage_lds<3, 4, NT>((float*)smem, w, v);
+    } else {
+        const float* const w[2] = {a.w2, a.wp[0]};
+        const float* const v[3] = {a.b1, a.b2, a.bp[0]};
+        stage_lds<2, 3, NT>((float*)smem, w, v);
+    }
+    for (int i = threadIdx.x; i < F * 64; i += NT) w1s[i] = a.w1[i];
+    float shift[F], scale[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { shift[f] = a.shift[f]; scale[f] = a.scale[f]; }
+    __syncthreads();
+    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
+        if (!first) load_ops(tile);
+        const int row = tile * 16 + j;
+        const bool ok = row < a.n;
+        RTile o, t;
+        rt_zero(o);
+        const float* w1h = lds_here(w1s);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float xn = ok ? (xv[f] + shift[f]) * scale[f] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 w = *(const float4*)(w1h + f * EMB + 16 * m + 4 * g);
+                o.v[m][0] = fmaf(xn, w.x, o.v[m][0]); o.v[m][1] = fmaf(xn, w.y, o.v[m][1]);
+                o.v[m][2] = fmaf(xn, w.z, o.v[m][2]); o.v[m][3] = fmaf(xn, w.w, o.v[m][3]);
+            }
+        }
+        rt_bias<true>(o, vecs, g);
+        rt_clear_unless(o, ok);
+        rt_store(o, a.e1, row, ok, g);
+        rt_mm<false>(t, o, 1.f, smem, lane);
+        rt_bias<true>(t, vecs + 64, g);
+        rt_clear_unless(t, ok);
+        rt_store(t, a.xo, row, ok, g);
+#pragma unroll
+        for (int k = 0; k < NPROJ; ++k) {
+            rt_mm<false>(o, t, 1.f, smem + (1 + k) * 64 * LDW, lane);
+            rt_bias<false>(o, vecs + (2 + k) * 64, g);
+            rt_store(o, a.po[k], row, ok, g);
+        }
+    }
+}
+struct EmbGroupArgs { int blk0[4]; EmbArgs v, c, k; };   // variables (F=14, two projections), constraints (4), cuts (6)
+#define EMB_LDS_FLOATS (ROWS_LDS_FLOATS(3, 4) + 14 * 64)
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < m.blk0[1]) emb_program<14, 2, NWAVES * 64>(m.v, smem, b, m.blk0[1]);
+    else if (b < m.blk0[2]) emb_program<4, 1, NWAVES * 64>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
+    else emb_program<6, 1, NWAVES * 64>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Program 2 (forward): receiver-side update of a PartialGraphConvolution after the edge pass (model.py:498-508, 568-573)
+//   A  = S Wf + deg_r bf                 (the per-edge Dense hoisted past the scatter-sum)        -> a_out (optional)
+//   Z1 = relu([s2*A | x_recv] W1 + b1)                                                             -> z1 (optional)
+//   X' = relu(Z1 W2 + b2)                                                                          -> out
+//   READOUT = false:  T = X' Wt (+ bt): the next convolution's projection                          -> t_out
+//   READOUT = true :  O1 = relu(X' Wt + bt) -> o1 (optional);  score = O1 . ws + bs (model.py:206-208) -> scores
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvFArgs {
+    const float* s; const int* seg_ptr; const float *wf, *bf; float* a_out;
+    const float *s2, *xrecv, *w1a, *w1b, *b1; float* z1;
+    const float *w2, *b2; float* out;
+    const float *wt, *bt; float* t_out;      // READOUT: wt/bt = readout Dense(64,relu), t_out = O1
+    const float *ws, *bs; float* scores;      // READOUT only
+    int n;
+};
+template <bool READOUT, int NT>
+__device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, int bid, int nblk) {
+    constexpr int NWAVES = NT / 64, NM = 5, NV = 5;   // Wf W1a W1b W2 Wt | bf b1 b2 bt ws
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int ntile = (a.n + 15) >> 4;
+    float* vecs = smem + NM * 64 * LDW;
+    int tile = bid * NWAVES + wv;
+    RTile s_in, xr;
+    int seg0 = 0, seg1 = 0;
+    auto load_ops = [&](int t) {
+        const int row = t * 16 + j;
+        const bool ok = row < a.n;
+        rt_load(s_in, a.s, row, ok, g);
+        rt_load(xr, a.xrecv, row, ok, g);
+        seg0 = ok ? a.seg_ptr[row] : 0; seg1 = ok ? a.seg_ptr[row + 1] : 0;
+    };
+    load_ops(tile);
+    {
+        const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
+        const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, READOUT ? a.ws : nullptr};
+        stage_lds<5, 5, NT>(smem, w, v);
+    }
+    const float s2 = *a.s2;
+    const float bs = READOUT ? *a.bs : 0.f;
+    __syncthreads();
+    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
+        if (!first) load_ops(tile);
+        const int row = tile * 16 + j;
+        const bool ok = row < a.n;
+        RTile t0, t1;
+        rt_mm<false>(t0, s_in, 1.f, smem, lane);
+        {   // + deg * bf
+            const float deg = (float)(seg1 - seg0);
+            const float* bfv = lds_here(vecs);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 b = *(const float4*)(bfv + 16 * m + 4 * g);
+                t0.v[m][0] = fmaf(deg, b.x, t0.v[m][0]); t0.v[m][1] = fmaf(deg, b.y, t0.v[m][1]);
+                t0.v[m][2] = fmaf(deg, b.z, t0.v[m][2]); t0.v[m][3] = fmaf(deg, b.w, t0.v[m][3]);
+            }
+        }
+        rt_clear_unless(t0, ok);
+        rt_store(t0, a.a_out, row, ok, g);
+        rt_mm2<false>(t1, t0, s2, smem + 64 * LDW, xr, smem + 2 * 64 * LDW, lane);
+        rt_bias<true>(t1, vecs + 64, g);
+        rt_clear_unless(t1, ok);
+        rt_store(t1, a.z1, row, ok, g);
+        rt_mm<false>(t0, t1, 1.f, smem + 3 * 64 * LDW, lane);
+        rt_bias<true>(t0, vecs + 2 * 64, g);
+        rt_clear_unless(t0, ok);
+        rt_store(t0, a.out, row, ok, g);
+        rt_mm<false>(t1, t0, 1.f, smem + 4 * 64 * LDW, lane);
+        if (!READOUT) {
+            rt_bias<false>(t1, vecs + 3 * 64, g);
+            rt_store(t1, a.t_out, row, ok, g);
+        } else {
+            rt_bias<true>(t1, vecs + 3 * 64, g);
+            rt_clear_unless(t1, ok);
+            rt_store(t1, a.t_out, row, ok, g);
+            float sum = 0.f;
+            const float* wsv = lds_here(vecs + 4 * 64);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 w = *(const float4*)(wsv + 16 * m + 4 * g);
+                sum = fmaf(t1.v[m][0], w.x, fmaf(t1.v[m][1], w.y, fmaf(t1.v[m][2], w.z, fmaf(t1.v[m][3], w.w, sum))));
+            }
+            sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+            if (g == 0 && ok) a.scores[row] = sum + bs;
+        }
+    }
+}
+template <int NWAVES, bool READOUT>
+__global__ __launch_bounds__(NWAVES * 64) void k_conv_fwd(ConvFArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    convf_program<READOUT, NWAVES * 64>(a, smem, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Program 3 (backward): receiver-side gradient of a PartialGraphConvolution, entered through the layer that consumed
+// its output X' (the next projection, or the readout):
+//   dX'  = (in W0^T) * (X' > 0)                                              -> g_out
+//   dZ1  = (dX' W2^T) * (Z1 > 0)                                             -> g_z1
+//   dx_r = dZ1 W1b^T                                                         -> g_xrecv
+//   dA   = s2 * (dZ1 W1a^T)                                                  -> g_a
+//   dS   = dA Wf^T                                                           -> g_s
+//   dP_recv = s1 * dS * N   (receiver-ordered half of the edge gradient, see k_edge_fwd)   -> g_precv
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvBArgs {
+    const float *in, *w0, *x_out; float* g_out;
+    const float *w2, *z1; float* g_z1;
+    const float* w1b; float* g_xrecv;
+    const float *w1a, *s2; float* g_a;
+    const float* wf; float* g_s;
+    const float *s1, *nrows; float* g_precv;
+    int n;
+};
+template <int NT>
+__device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, int bid, int nblk) {
+    constexpr int NWAVES = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int ntile = (a.n + 15) >> 4;
+    int tile = bid * NWAVES + wv;
+    RTile in, m0, m1, nr;
+    auto load_ops = [&](int t) {
+        const int row = t * 16 + j;
+        const bool ok = row < a.n;
+        rt_load(in, a.in, row, ok, g);
+        rt_load(m0, a.x_out, row, ok, g);
+        rt_load(m1, a.z1, row, ok, g);
+        rt_load(nr, a.nrows, row, ok, g);
+    };
+    load_ops(tile);
+    {
+        const float* const w[5] = {a.w0, a.w2, a.w1b, a.w1a, a.wf};
+        const float* const v[1] = {nullptr};
+        stage_lds<5, 1, NT>(smem, w, v);
+    }
+    const float s2 = *a.s2, s1 = *a.s1;
+    __syncthreads();
+    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
+        if (!first) load_ops(tile);
+        const int row = tile * 16 + j;
+        const bool ok = row < a.n;
+        RTile t0, t1;
+        rt_mm<true>(t0, in, 1.f, smem, lane);
+        rt_mask(t0, m0);
+        rt_store(t0, a.g_out, row, ok, g);
+        rt_mm<true>(t1, t0, 1.f, smem + 64 * LDW, lane);
+        rt_mask(t1, m1);
+        rt_store(t1, a.g_z1, row, ok, g);
+        rt_mm<true>(t0, t1, 1.f, smem + 2 * 64 * LDW, lane);
+        rt_store(t0, a.g_xrecv, row, ok, g);
+        rt_mm<true>(t0, t1, 1.f, smem + 3 * 64 * LDW, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t0.v[m][i] *= s2;
+        rt_store(t0, a.g_a, row, ok, g);
+        rt_mm<true>(t1, t0, 1.f, smem + 4 * 64 * LDW, lane);
+        rt_store(t1, a.g_s, row, ok, g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t1.v[m][i] = s1 * t1.v[m][i] * nr.v[m][i];
+        rt_store(t1, a.g_precv, row, ok, g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Program 4 (backward): gradient reaching a raw embedding X (it fed one or two projections, and the concat of a
+// convolution whose share `add` is already in place), then through the embedding's second layer:
+//   dX  = (in_a Wa^T [+ in_b Wb^T] + add) * (X > 0)                          -> g_x   (may alias add)
+//   dE1 = dX W2^T                      (masked later, inside the first layer's weight-gradient kernel)   -> g_e1
+// ---------------------------------------------------------------------------------------------------------------
+struct TailBArgs {
+    const float *in_a, *wa, *in_b, *wb, *add, *x; float* g_x;
+    const float* w2; float* g_e1;
+    int n;
+};
+template <bool HAS_INB, int NT>
+__device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, int bid, int nblk) {
+    constexpr int NWAVES = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int ntile = (a.n + 15) >> 4;
+    int tile = bid * NWAVES + wv;
+    RTile ia, ib, ad, mk;
+    auto load_ops = [&](int t) {
+        const int row = t * 16 + j;
+        const bool ok = row < a.n;
+        rt_load(ia, a.in_a, row, ok, g);
+        if (HAS_INB) rt_load(ib, a.in_b, row, ok, g);
+        rt_load(ad, a.add, row, ok, g);
+        rt_load(mk, a.x, row, ok, g);
+    };
+    load_ops(tile);
+    const float* const v[1] = {nullptr};
+    if (HAS_INB) { const float* const w[3] = {a.wa, a.w2, a.wb}; stage_lds<3, 1, NT>(smem, w, v); }
+    else { const float* const w[2] = {a.wa, a.w2}; stage_lds<2, 1, NT>(smem, w, v); }
+    __syncthreads();
+    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
+        if (!first) load_ops(tile);
+        const int row = tile * 16 + j;
+        const bool ok = row < a.n;
+        RTile t0, t1;
+        if (HAS_INB) rt_mm2<true>(t0, ia, 1.f, smem, ib, smem + 2 * 64 * LDW, lane);
+        else rt_mm<true>(t0, ia, 1.f, smem, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t0.v[m][i] += ad.v[m][i];
+        rt_mask(t0, mk);
+        rt_store(t0, a.g_x, row, ok, g);
+        rt_mm<true>(t1, t0, 1.f, smem + 64 * LDW, lane);
+        rt_store(t1, a.g_e1, row, ok, g);
+    }
+}
+
+// backward launches: a receiver-gradient program, optionally with a tail program over another row set beside it ...
+struct ConvBGroupArgs { int blk0[3]; ConvBArgs cb; TailBArgs tail; };
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_conv_bwd(ConvBGroupArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < m.blk0[1]) convb_program<NWAVES * 64>(m.cb, smem, b, m.blk0[1]);
+    else tailb_program<false, NWAVES * 64>(m.tail, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
+}
+// ... and the two last tails together: `a` sums two projections (the raw variable embedding fed two convolutions)
+struct TailGroupArgs { int blk0[3]; TailBArgs a, b; };
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_tail_bwd(TailGroupArgs m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < m.blk0[1]) tailb_program<true, NWAVES * 64>(m.a, smem, b, m.blk0[1]);
+    else tailb_program<false, NWAVES * 64>(m.b, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
+}
