@@ -543,7 +543,7 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
 // launch every collected weight-gradient job as ONE grouped kernel
 static int flush_wg(JobList& jl, hipStream_t st) {
     if (jl.wg.nblocks > 0) {
-        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(256), 0, st, jl.wg);
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(64), 0, st, jl.wg);
         LAUNCHCHK();
     }
     jl.wg.njobs = 0; jl.wg.nblocks = 0;

@@ -3,7 +3,7 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // The loss head (model_trainer.py:271) and the gradient of the readout tail Dense(64->1) (model.py:208); the forward of
-// that Dense closes the last forward chain (CH_SCORE in k_chain.hpp).
+// that Dense closes the last forward row program (convf_program<READOUT> in k_rows.hpp).
 // ---------------------------------------------------------------------------------------------------------------
 // MSE head (model_trainer.py:271): loss = scale * sum_k (score_k - y_k)^2, d_score_k = 2*scale*(score_k - y_k).  One block.
 __global__ __launch_bounds__(256) void k_mse(const float* __restrict__ score, const float* __restrict__ target, float scale,

@@ -3,7 +3,7 @@
 
 // ---------------------------------------------------------------------------------------------------------------
 // First embedding layer relu(((x+shift)*scale) @ W[f,64] + b) (model.py:174-177 and var/cut twins): its forward opens
-// the forward chains (CH_EMBED1 in k_chain.hpp); here its weight gradient on the VALU (K = f <= 14).
+// the forward embedding programs (emb_program in k_rows.hpp); here its weight gradient on the VALU (K = f <= 14).
 // ---------------------------------------------------------------------------------------------------------------
 // gradient of the first embedding layer's weights: dW[f][j] = sum_r xn[r][f] * dPre[r][j], db[j] = sum_r dPre[r][j]
 // with dPre = dY * (Y > 0).  One block per chunk of rows; per-block partial slab [(F+1)*64] (row F = bias).  The three
@@ -46,85 +46,89 @@ __global__ __launch_bounds__(256) void k_embed1_wgrad(Emb1Args a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
-// Grouped launch: one job per (X, D) pair, one block per 256-row chunk of a job.  Wave w owns the 32x32 quadrant
-// (w>>1, w&1) of G and never talks to the other waves: rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four
-// rows per instruction), and both operands come straight from global memory -- lane (m, g) loads the float2 at columns
-// 2m, 2m+1 of its quadrant's half of row 4*step+g, which serves two A (or B) variants, so one X load and one D load
-// feed four MFMAs.  No LDS, no barriers; loads run one 32-row batch ahead of the MFMAs.  Per-block partial slab
-// [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
+// Grouped launch: one job per (X, D) pair, ONE WAVE per 256-row chunk of a job (64-thread blocks; waves never talk to
+// each other).  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
+// straight from global memory, every row read exactly once as whole 256-B lines: lane (m, g) loads the float4 at columns
+// 4m..4m+3 of row 4*step+g of X and of D; component va of the X load and component vb of the D load feed accumulator
+// (va, vb), so two loads feed 16 MFMAs.  No LDS, no barriers; loads run one 16-row batch ahead of the MFMAs.
+// Per-chunk partial slab [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
 // ---------------------------------------------------------------------------------------------------------------
 #define WG_ROWS 256
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 24
-#define WG_STEPS 8   // 4-row MFMA steps per batch of loads
+#define WG_STEPS 4   // 4-row MFMA steps per batch of loads
 struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float* d2; int n; int blk0; int slab0; };
 struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
-struct WgBatch { float2 x[WG_STEPS], d[WG_STEPS], e[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
+struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS], e[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
 
-// EXTRA: 0 = none, 1 = degree-weighted column sum (e.x = degree of the row), 2 = column sum of a second matrix (e = Q row)
+// EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f), 2 = column sum of a second matrix
+// (Q -> d w_edge)
 template <int EXTRA>
-__device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int xcol, int dcol) {
+__device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int col) {
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) {
         const int r = row0 + 4 * s + g;
-        t.x[s] = t.d[s] = t.e[s] = make_float2(0.f, 0.f);
+        t.x[s] = t.d[s] = t.e[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         t.p0[s] = t.p1[s] = 0;
         if (r < rend) {
-            t.x[s] = *(const float2*)(jb.x + (size_t)r * EMB + xcol);
-            t.d[s] = *(const float2*)(jb.d + (size_t)r * EMB + dcol);
+            t.x[s] = *(const float4*)(jb.x + (size_t)r * EMB + col);
+            t.d[s] = *(const float4*)(jb.d + (size_t)r * EMB + col);
             if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
-            if (EXTRA == 2) t.e[s] = *(const float2*)(jb.d2 + (size_t)r * EMB + dcol);
+            if (EXTRA == 2) t.e[s] = *(const float4*)(jb.d2 + (size_t)r * EMB + col);
         }
     }
 }
 
 template <int EXTRA>
 __device__ __forceinline__ void wg_body(const WgJob& jb, float* __restrict__ slab, int rbeg, int rend) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int qi = wv >> 1, qj = wv & 1, m = lane & 15, g = lane >> 4;
-    const int xcol = qi * 32 + 2 * m, dcol = qj * 32 + 2 * m;
-    f32x4w acc[2][2];
+    const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4, col = 4 * m;
+    f32x4w acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = f32x4w{0.f, 0.f, 0.f, 0.f};
-    float2 cs = make_float2(0.f, 0.f), ce = cs;
+    for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ce = cs;
     WgBatch cur, nxt;
-    wg_load<EXTRA>(cur, jb, rbeg, rend, g, xcol, dcol);
+    wg_load<EXTRA>(cur, jb, rbeg, rend, g, col);
     for (int row0 = rbeg; row0 < rend; row0 += 4 * WG_STEPS) {
-        wg_load<EXTRA>(nxt, jb, row0 + 4 * WG_STEPS, rend, g, xcol, dcol);   // past the chunk: all lanes load nothing
+        wg_load<EXTRA>(nxt, jb, row0 + 4 * WG_STEPS, rend, g, col);   // past the chunk: all lanes load nothing
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].x, cur.d[s].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].x, cur.d[s].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].y, cur.d[s].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.x[s].y, cur.d[s].y, acc[1][1], 0, 0, 0);
-            cs.x += cur.d[s].x; cs.y += cur.d[s].y;
+            const float xa[4] = {cur.x[s].x, cur.x[s].y, cur.x[s].z, cur.x[s].w};
+            const float db[4] = {cur.d[s].x, cur.d[s].y, cur.d[s].z, cur.d[s].w};
+#pragma unroll
+            for (int va = 0; va < 4; ++va)
+#pragma unroll
+                for (int vb = 0; vb < 4; ++vb)
+                    acc[va][vb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[va], db[vb], acc[va][vb], 0, 0, 0);
+            cs.x += db[0]; cs.y += db[1]; cs.z += db[2]; cs.w += db[3];
             if (EXTRA == 1) {
                 const float deg = (float)(cur.p1[s] - cur.p0[s]);
-                ce.x = fmaf(deg, cur.d[s].x, ce.x); ce.y = fmaf(deg, cur.d[s].y, ce.y);
+                ce.x = fmaf(deg, db[0], ce.x); ce.y = fmaf(deg, db[1], ce.y); ce.z = fmaf(deg, db[2], ce.z); ce.w = fmaf(deg, db[3], ce.w);
             }
-            if (EXTRA == 2) { ce.x += cur.e[s].x; ce.y += cur.e[s].y; }
+            if (EXTRA == 2) { ce.x += cur.e[s].x; ce.y += cur.e[s].y; ce.z += cur.e[s].z; ce.w += cur.e[s].w; }
         }
         cur = nxt;
     }
     const float sx = jb.sx ? *jb.sx : 1.f;
-    // acc[va][vb][t] = G[qi*32 + 2*(4g+t) + va][qj*32 + 2m + vb]
+    // acc[va][vb][t] = G[4*(4g+t) + va][4m + vb]
 #pragma unroll
-    for (int va = 0; va < 2; ++va)
+    for (int va = 0; va < 4; ++va)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            *(float2*)(slab + (qi * 32 + 2 * (4 * g + t) + va) * EMB + dcol) = make_float2(acc[va][0][t] * sx, acc[va][1][t] * sx);
-    // column sums: fold the four row slots (g) of the wave; the qi == 0 waves own them
-    cs.x += __shfl_xor(cs.x, 16); cs.y += __shfl_xor(cs.y, 16); ce.x += __shfl_xor(ce.x, 16); ce.y += __shfl_xor(ce.y, 16);
-    cs.x += __shfl_xor(cs.x, 32); cs.y += __shfl_xor(cs.y, 32); ce.x += __shfl_xor(ce.x, 32); ce.y += __shfl_xor(ce.y, 32);
-    if (qi == 0 && g == 0) {
-        *(float2*)(slab + EMB * EMB + dcol) = cs;
-        *(float2*)(slab + EMB * EMB + EMB + dcol) = ce;
+            *(float4*)(slab + (4 * (4 * g + t) + va) * EMB + col) =
+                make_float4(acc[va][0][t] * sx, acc[va][1][t] * sx, acc[va][2][t] * sx, acc[va][3][t] * sx);
+    // column sums: fold the four row slots (g) of the wave
+    float* c8[8] = {&cs.x, &cs.y, &cs.z, &cs.w, &ce.x, &ce.y, &ce.z, &ce.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { *c8[i] += __shfl_xor(*c8[i], 16); *c8[i] += __shfl_xor(*c8[i], 32); }
+    if (g == 0) {
+        *(float4*)(slab + EMB * EMB + col) = cs;
+        *(float4*)(slab + EMB * EMB + EMB + col) = ce;
     }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad(WgArgs a) {
+__global__ __launch_bounds__(64) void k_wgrad(WgArgs a) {
     int ji = 0;
     while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
     const WgJob jb = a.job[ji];
