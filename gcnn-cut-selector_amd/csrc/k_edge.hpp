@@ -15,21 +15,12 @@ struct EdgeArgs {
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
     const float* d_s;                              // send pass: dS [R,64], gathered by oth
     const int* xpos;                               // send pass: position of each edge in the receiver-ordered list
-    unsigned long long* mask;                      // [E] ReLU bits in receiver order (nibble c = channels 4c..4c+3): fwd writes, send pass reads
+    unsigned long long* mask;                      // [E] ReLU bits in receiver order (bit 16k + c = channel 4c + k): fwd writes, send pass reads
     float* out;                                    // S (fwd) / dP_send
     float* dw_rows;                                // send pass: Q [n_send,64], per-sender share of d w_edge
     float* cnt_rows;                               // fwd (SAVE): N[r] = number of active edges per channel
     int n_recv;
 };
-
-// OR over the 16 lanes of a DPP row (= the 16-lane group that serves one edge): rotate-and-OR by 1, 2, 4, 8
-__device__ __forceinline__ unsigned row_or16(unsigned x) {
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false);  // row_ror:1
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false);  // row_ror:2
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false);  // row_ror:4
-    x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);  // row_ror:8
-    return x;
-}
 
 template <int SLOTS>
 __device__ __forceinline__ float4 slot_reduce(float4 v) {
@@ -44,9 +35,8 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
 
 // Forward edge pass.  relu(s1*J) = s1*max(J,0) for s1 >= 0 and s1*min(J,0) for s1 < 0, so the scale is applied once per
 // receiver.  J_e = (c_e*w + P_oth[oth_e]) + P_own[r].
-// SAVE also emits what the backward pass needs: per edge one 64-bit word (nibble c = the ReLU bits of channels
-// 4c..4c+3, assembled across the edge's 16 lanes with DPP row rotations) and per receiver/channel the number N of
-// active edges.  Because dS[r] is
+// SAVE also emits what the backward pass needs: per edge one 64-bit word (bit 16k + c = the ReLU bit of channel 4c + k,
+// cut out of four wave-wide compare masks) and per receiver/channel the number N of active edges.  Because dS[r] is
 // constant over a receiver's segment, dP_recv[r] = s1*dS[r]*N[r]: the receiver-ordered half of the backward pass is an
 // element-wise epilogue (of the chain that produces dS), not an edge pass.
 template <int SLOTS, bool SAVE, bool NEG>
@@ -56,6 +46,10 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
     const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
     const float4 w = *(const float4*)(a.w_edge + ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
+    // storing lane t = gl (< 4*SLOTS) of a receiver handles the edge of step-iteration u = t / SLOTS, slot = t % SLOTS,
+    // whose bits sit at [16f, 16f+16) of the wave masks, f = the receiver's first 16-lane group + slot
+    const int st_u = (gl / SLOTS) & 3;
+    const unsigned st_sh = 16u * ((gbase >> 4) + gl % SLOTS);
 
     const int nwork = (a.n_recv + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
@@ -70,9 +64,8 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                 int o = 0; float c = 0.f;
                 if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
                 const int cnt = min(G, end - base);
-                unsigned npk = 0;   // packed byte counters: at most 16 edges per slot per chunk, no overflow
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4]; unsigned nib[4] = {0u, 0u, 0u, 0u};
+                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4]; unsigned long long bal[4][4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int i = i0 + u * SLOTS + slot;
@@ -85,37 +78,37 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                         if (ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
+                        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
                         if (ok[u]) {
-                            float h0 = fmaf(ci[u], w.x, p[u].x) + pown.x, h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
-                            float h2 = fmaf(ci[u], w.z, p[u].z) + pown.z, h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
+                            h0 = fmaf(ci[u], w.x, p[u].x) + pown.x; h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
+                            h2 = fmaf(ci[u], w.z, p[u].z) + pown.z; h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
                             h0 = NEG ? fminf(h0, 0.f) : fmaxf(h0, 0.f); h1 = NEG ? fminf(h1, 0.f) : fmaxf(h1, 0.f);
                             h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
                             acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
-                            if (SAVE) {
-                                // active bit: h > 0 read off the float's bit pattern (+0 -> 0, anything positive -> 1)
-                                unsigned b0, b1, b2, b3;
-                                if (NEG) { b0 = h0 < 0.f; b1 = h1 < 0.f; b2 = h2 < 0.f; b3 = h3 < 0.f; }
-                                else {
-                                    b0 = (__float_as_uint(h0) + 0x7fffffffu) >> 31; b1 = (__float_as_uint(h1) + 0x7fffffffu) >> 31;
-                                    b2 = (__float_as_uint(h2) + 0x7fffffffu) >> 31; b3 = (__float_as_uint(h3) + 0x7fffffffu) >> 31;
-                                }
-                                nib[u] = b0 | (b1 << 1) | (b2 << 2) | (b3 << 3);
-                                npk += (nib[u] * 0x00204081u) & 0x01010101u;   // four 8-bit counters, one per channel
-                            }
+                        }
+                        if (SAVE) {
+                            // One compare per channel gives the active bits of all 64 lanes (= 4 edges x 16 lanes) as a wave
+                            // mask; the edge served by 16-lane group f owns bits [16f, 16f+16) of each.
+                            const bool a0 = NEG ? h0 < 0.f : h0 > 0.f, a1 = NEG ? h1 < 0.f : h1 > 0.f;
+                            const bool a2 = NEG ? h2 < 0.f : h2 > 0.f, a3 = NEG ? h3 < 0.f : h3 > 0.f;
+                            n0 += a0; n1 += a1; n2 += a2; n3 += a3;
+                            bal[u][0] = __ballot(a0); bal[u][1] = __ballot(a1); bal[u][2] = __ballot(a2); bal[u][3] = __ballot(a3);
                         }
                     }
                     if (SAVE) {
-                        // each lane drops its nibble at bits 4*(c&7) of the low (c < 8) or high word; OR over the row
+                        // The step's 4*SLOTS edges of this receiver are consecutive in the list: lane t of the receiver's
+                        // lanes assembles the word of edge t = u*SLOTS + slot (bit 16k + c <=> channel 4c + k active)
+                        // and ONE store instruction writes them all.
+                        unsigned f[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const unsigned sh = nib[u] << (4 * (cl & 7));
-                            const unsigned lo = row_or16(cl < 8 ? sh : 0u), hi = row_or16(cl < 8 ? 0u : sh);
-                            if (ok[u] && cl == 0)
-                                a.mask[base + i0 + u * SLOTS + slot] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned long long b = st_u == 0 ? bal[0][k] : (st_u == 1 ? bal[1][k] : (st_u == 2 ? bal[2][k] : bal[3][k]));
+                            f[k] = (unsigned)(b >> st_sh) & 0xffffu;
                         }
+                        if (gl < 4 * SLOTS && i0 + gl < cnt)
+                            a.mask[base + i0 + gl] = (unsigned long long)(f[0] | (f[1] << 16)) | ((unsigned long long)(f[2] | (f[3] << 16)) << 32);
                     }
                 }
-                if (SAVE) { n0 += npk & 255u; n1 += (npk >> 8) & 255u; n2 += (npk >> 16) & 255u; n3 += npk >> 24; }
             }
             acc = slot_reduce<SLOTS>(acc);
             if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
@@ -153,6 +146,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
     const float s1 = *a.s1, esh = *a.e_shift, esc = *a.e_scale;
+    const unsigned bit_a = 1u << cl, bit_b = 1u << (16 + cl);   // mask word: bit 16k + c <=> channel 4c + k (see k_edge_fwd)
     const int nwork = (a.n_recv + RPW - 1) / RPW;
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
         const int u = item * RPW + lane / G;
@@ -169,17 +163,15 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
                 }
                 const int cnt = min(G, end - base);
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 d[4]; unsigned mb[4];
+                    int oi[4]; float ci[4]; bool ok[4]; float4 d[4]; unsigned wlo[4], whi[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int i = i0 + v * SLOTS + slot;
                         ok[v] = i < cnt;
                         const int src = gbase + (ok[v] ? i : 0);
                         oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);
-                        const unsigned wlo = __shfl(mlo, src), whi = __shfl(mhi, src);  // both by every lane: a shuffle
-                        const unsigned word = cl < 8 ? wlo : whi;                        // must not sit under a lane mask
-                        mb[v] = ok[v] ? (word >> (4 * (cl & 7))) & 15u : 0u;
-                    }
+                        wlo[v] = __shfl(mlo, src); whi[v] = __shfl(mhi, src);   // by every lane: a shuffle must not sit
+                    }                                                           // under a lane mask
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         d[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -187,8 +179,9 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
                     }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const float t0 = (mb[v] & 1u) ? d[v].x : 0.f, t1 = (mb[v] & 2u) ? d[v].y : 0.f;
-                        const float t2 = (mb[v] & 4u) ? d[v].z : 0.f, t3 = (mb[v] & 8u) ? d[v].w : 0.f;
+                        // rows of inactive slots are zero, so their mask bits do not matter
+                        const float t0 = (wlo[v] & bit_a) ? d[v].x : 0.f, t1 = (wlo[v] & bit_b) ? d[v].y : 0.f;
+                        const float t2 = (whi[v] & bit_a) ? d[v].z : 0.f, t3 = (whi[v] & bit_b) ? d[v].w : 0.f;
                         acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
                         dw.x = fmaf(ci[v], t0, dw.x); dw.y = fmaf(ci[v], t1, dw.y); dw.z = fmaf(ci[v], t2, dw.z); dw.w = fmaf(ci[v], t3, dw.w);
                     }
