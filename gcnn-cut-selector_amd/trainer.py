@@ -134,10 +134,9 @@ def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam
 class GraphedTrainStep:
     """One training step on a FIXED prepared batch, captured once into a hipGraph and replayed.
 
-    A step is ~35 kernel launches plus event edges between three streams; issued eagerly the host needs ~0.3-0.5 ms for
-    them, as long as the GPU needs to run them.  Capture (torch.cuda.CUDAGraph over the same `train_step`, whose C side
-    forks/joins its side streams with events, which capture turns into parallel graph branches) removes the host from the
-    loop.  Everything step-dependent lives on the device (Adam's step counter and learning rate: `Adam.apply_flat_dev`).
+    A step is 20 kernel launches on one stream; capture (torch.cuda.CUDAGraph over the same `train_step`) removes the host
+    from the loop.  Everything step-dependent lives on the device (Adam's step counter and learning rate:
+    `Adam.apply_flat_dev`).  Measured: no faster than eager issue -- the GPU-side launch sequence is the limit.
     The graph is tied to the batch's buffers and sizes: use it when batches have a fixed shape / are replayed (benchmarks,
     fixed-capacity loaders); variable-shape training uses the eager `train_step`."""
 
