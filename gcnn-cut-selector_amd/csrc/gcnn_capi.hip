@@ -104,7 +104,6 @@ struct Work {
     size_t total;
 };
 static inline size_t al4(size_t x) { return (x + 3) & ~(size_t)3; }
-#define EMB1_ROWS 128
 
 static size_t wg_slabs(const gcnn_dims* d) {  // total number of wgrad slabs over all 22 jobs
     const int C = d->n_cons, V = d->n_vars, K = d->n_cuts;
@@ -540,15 +539,6 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
     if (gb) rd(src + EMB * EMB, gb, EMB);
     if (g2) rd(src + EMB * EMB + EMB, g2, EMB);
 }
-// launch every collected weight-gradient job as ONE grouped kernel
-static int flush_wg(JobList& jl, hipStream_t st) {
-    if (jl.wg.nblocks > 0) {
-        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks), dim3(64), 0, st, jl.wg);
-        LAUNCHCHK();
-    }
-    jl.wg.njobs = 0; jl.wg.nblocks = 0;
-    return 0;
-}
 static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int stride, int len) {
     if (nparts <= 0) return;
     RdJob& r = jl.rd.job[jl.rd.njobs++];
@@ -669,30 +659,27 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         tail(m.b, G.PL1, p + poff(P_CONV0 + C_WL), nullptr, nullptr, G.Xc, A.Xc, P_CONS, G.E1c, d->n_cons);
         if ((rc = launch_tail_bwd(m, st))) return rc;
     }
-    // Weight gradients: every operand pair now exists, so ALL of them go out as three grouped launches -- the first
-    // embedding layers (VALU, K = f <= 14), the 22 [64,64] products (MFMA), and the fixed-order reduction of the slabs.
-    // (Running them beside the critical path on side streams was slower: a cross-stream event edge costs 7-14 us here.)
-    {
-        Emb1Args ea; memset(&ea, 0, sizeof(ea)); ea.rows_per_block = EMB1_ROWS;
-        int nblk = 0;
-        for (int i = 0; i < 3; ++i) {
-            if (em[i].n <= 0) continue;
-            ea.job[ea.njobs++] = Emb1Job{em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1,
-                                         w.emb_partial[i], em[i].n, em[i].f, nblk};
-            nblk += w.emb_nblk[i];
-            // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
-            add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
-            add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
-        }
-        if (nblk > 0) {
-            hipLaunchKernelGGL(k_embed1_wgrad, dim3(nblk), dim3(256), 0, st, ea);
-            LAUNCHCHK();
-        }
+    // Weight gradients: every operand pair now exists, so ALL of them go out as two grouped launches -- the 22 [64,64]
+    // products (MFMA) together with the three first embedding layers (VALU, K = f <= 14), then the fixed-order reduction of
+    // the slabs.  (Running them beside the critical path on side streams was slower: a cross-stream event edge costs
+    // 7-14 us here.)
+    Emb1Args ea; memset(&ea, 0, sizeof(ea));
+    for (int i = 0; i < 3; ++i) {
+        if (em[i].n <= 0) continue;
+        ea.job[ea.njobs++] = Emb1Job{em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1,
+                                     w.emb_partial[i], em[i].n, em[i].f, ea.nblocks};
+        ea.nblocks += w.emb_nblk[i];
+        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
+        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
+        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
     }
     for (int i = 0; i < 3; ++i)
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
-    if ((rc = flush_wg(jl, st))) return rc;
+    if (jl.wg.nblocks + ea.nblocks > 0) {
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64), 0, st, jl.wg, ea);
+        LAUNCHCHK();
+    }
     if (jl.rdblk > 0) {
         hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
         LAUNCHCHK();

@@ -6,42 +6,41 @@
 // the forward embedding programs (emb_program in k_rows.hpp); here its weight gradient on the VALU (K = f <= 14).
 // ---------------------------------------------------------------------------------------------------------------
 // gradient of the first embedding layer's weights: dW[f][j] = sum_r xn[r][f] * dPre[r][j], db[j] = sum_r dPre[r][j]
-// with dPre = dY * (Y > 0).  One block per chunk of rows; per-block partial slab [(F+1)*64] (row F = bias).  The three
-// embeddings (F = 4, 14, 6) share one grouped launch: blockIdx picks the group.
+// with dPre = dY * (Y > 0).  One WAVE per chunk of EMB1_ROWS rows, lane = output column; per-chunk partial slab
+// [(F+1)*64] (row F = bias).  The three embeddings (F = 4, 14, 6) are extra block ranges of the k_wgrad launch below.
+#define EMB1_ROWS 64
 struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; };
-struct Emb1Args { int njobs; int rows_per_block; Emb1Job job[3]; };
+struct Emb1Args { int njobs; int nblocks; Emb1Job job[3]; };
 
 template <int F>
-__device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int lb, int rows_per_block, float* red) {
-    const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
-    float acc[F + 1];
+__device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int lb) {
+    const int col = threadIdx.x & 63;
+    float acc[F + 1], shift[F], scale[F];
 #pragma unroll
     for (int f = 0; f <= F; ++f) acc[f] = 0.f;
-    const int r0 = lb * rows_per_block;
-    const int r1 = min(jb.n, r0 + rows_per_block);
-#pragma unroll 4
-    for (int r = r0 + part; r < r1; r += 4) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) { shift[f] = jb.shift[f]; scale[f] = jb.scale[f]; }
+    const int r0 = lb * EMB1_ROWS;
+    const int r1 = min(jb.n, r0 + EMB1_ROWS);
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
         float d = jb.dy[(size_t)r * EMB + col];
         d = jb.yact[(size_t)r * EMB + col] > 0.f ? d : 0.f;
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] = fmaf((jb.x[(size_t)r * F + f] + jb.shift[f]) * jb.scale[f], d, acc[f]);
+        for (int f = 0; f < F; ++f) acc[f] = fmaf((jb.x[(size_t)r * F + f] + shift[f]) * scale[f], d, acc[f]);   // x: wave-uniform
         acc[F] += d;
     }
 #pragma unroll
-    for (int f = 0; f <= F; ++f) red[part * 15 * EMB + f * EMB + col] = acc[f];
-    __syncthreads();
-    for (int i = threadIdx.x; i < (F + 1) * EMB; i += 256)
-        jb.partial[(size_t)lb * (F + 1) * EMB + i] = (red[i] + red[15 * EMB + i]) + (red[2 * 15 * EMB + i] + red[3 * 15 * EMB + i]);
+    for (int f = 0; f <= F; ++f) jb.partial[(size_t)lb * (F + 1) * EMB + f * EMB + col] = acc[f];
 }
-__global__ __launch_bounds__(256) void k_embed1_wgrad(Emb1Args a) {
-    __shared__ float red[4 * 15 * EMB];
+__device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b) {
     int ji = 0;
-    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
+    while (ji + 1 < a.njobs && b >= a.job[ji + 1].blk0) ++ji;
     const Emb1Job jb = a.job[ji];
-    const int lb = blockIdx.x - jb.blk0;
-    if (jb.f == 4) embed1_wgrad_body<4>(jb, lb, a.rows_per_block, red);
-    else if (jb.f == 6) embed1_wgrad_body<6>(jb, lb, a.rows_per_block, red);
-    else embed1_wgrad_body<14>(jb, lb, a.rows_per_block, red);
+    const int lb = b - jb.blk0;
+    if (jb.f == 4) embed1_wgrad_body<4>(jb, lb);
+    else if (jb.f == 6) embed1_wgrad_body<6>(jb, lb);
+    else embed1_wgrad_body<14>(jb, lb);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -128,7 +127,11 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* __restrict__ sla
     }
 }
 
-__global__ __launch_bounds__(64) void k_wgrad(WgArgs a) {
+__global__ __launch_bounds__(64) void k_wgrad(WgArgs a, Emb1Args e) {
+    if ((int)blockIdx.x >= a.nblocks) {   // the (short) first-embedding-layer chunks come after the long MFMA chunks
+        embed1_wgrad_block(e, blockIdx.x - a.nblocks);
+        return;
+    }
     int ji = 0;
     while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
     const WgJob jb = a.job[ji];

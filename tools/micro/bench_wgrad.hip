@@ -39,10 +39,10 @@ int main() {
             blk += cdiv(c.n[j], WG_ROWS);
         }
         a.nblocks = blk;
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64), 0, 0, a);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64), 0, 0, a, Emb1Args{});
         CK(hipEventRecord(e0, 0));
         const int R = 50;
-        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64), 0, 0, a);
+        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64), 0, 0, a, Emb1Args{});
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-20s blocks %4d  %.2f us/launch\n", c.name, blk, ms * 1000 / R);
