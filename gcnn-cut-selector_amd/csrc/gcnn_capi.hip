@@ -107,7 +107,7 @@ static inline size_t al4(size_t x) { return (x + 3) & ~(size_t)3; }
 
 static size_t wg_slabs(const gcnn_dims* d) {  // total number of wgrad slabs over all 22 jobs
     const int C = d->n_cons, V = d->n_vars, K = d->n_cuts;
-    const int bc = cdiv(C, WG_ROWS), bv = cdiv(V, WG_ROWS), bk = cdiv(K, WG_ROWS);
+    const int bc = cdiv(C, WG_ROWS * WG_WAVES), bv = cdiv(V, WG_ROWS * WG_WAVES), bk = cdiv(K, WG_ROWS * WG_WAVES);
     // jobs per row set (see gcnn_backward): cons 7, var 8, cut 7; 8 each leaves slack
     return (size_t)bc * 8 + (size_t)bv * 8 + (size_t)bk * 8;
 }
@@ -526,7 +526,7 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
                    int n, float* gw, float* gb, float* g2, float* partial) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
     WgJob& j = jl.wg.job[jl.wg.njobs++];
-    const int nb = cdiv(n, WG_ROWS);
+    const int nb = cdiv(n, WG_ROWS * WG_WAVES);   // blocks = slabs: four 256-row chunks each
     j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.d2 = d2; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
     const float* src = partial + (size_t)jl.nslab * WG_SLAB;
     jl.wg.nblocks += nb; jl.nslab += nb;
@@ -613,8 +613,6 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
     if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
-    if ((size_t)cdiv(d->n_cons, WG_ROWS) * 8 + (size_t)cdiv(d->n_vars, WG_ROWS) * 8 + (size_t)cdiv(d->n_cuts, WG_ROWS) * 8 > wg_slabs(d))
-        return GCNN_E_WORKSPACE;
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
         {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
@@ -667,8 +665,8 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     for (int i = 0; i < 3; ++i) {
         if (em[i].n <= 0) continue;
         ea.job[ea.njobs++] = Emb1Job{em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1,
-                                     w.emb_partial[i], em[i].n, em[i].f, ea.nblocks};
-        ea.nblocks += w.emb_nblk[i];
+                                     w.emb_partial[i], em[i].n, em[i].f, ea.nblocks, w.emb_nblk[i]};
+        ea.nblocks += cdiv(w.emb_nblk[i], WG_WAVES);
         // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
         add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
         add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
@@ -677,7 +675,10 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
     if (jl.wg.nblocks + ea.nblocks > 0) {
-        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64), 0, st, jl.wg, ea);
+        static bool attr_set = false;
+        const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64 * WG_WAVES), smem, st, jl.wg, ea);
         LAUNCHCHK();
     }
     if (jl.rdblk > 0) {

@@ -9,7 +9,8 @@
 // with dPre = dY * (Y > 0).  One WAVE per chunk of EMB1_ROWS rows, lane = output column; per-chunk partial slab
 // [(F+1)*64] (row F = bias).  The three embeddings (F = 4, 14, 6) are extra block ranges of the k_wgrad launch below.
 #define EMB1_ROWS 64
-struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; };
+#define WG_WAVES 4    // waves (= chunks) per block of the k_wgrad launch
+struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; int nchunk; };
 struct Emb1Args { int njobs; int nblocks; Emb1Job job[3]; };
 
 template <int F>
@@ -37,7 +38,8 @@ __device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b) {
     int ji = 0;
     while (ji + 1 < a.njobs && b >= a.job[ji + 1].blk0) ++ji;
     const Emb1Job jb = a.job[ji];
-    const int lb = b - jb.blk0;
+    const int lb = (b - jb.blk0) * WG_WAVES + (threadIdx.x >> 6);   // this wave's chunk
+    if (lb >= jb.nchunk) return;
     if (jb.f == 4) embed1_wgrad_body<4>(jb, lb);
     else if (jb.f == 6) embed1_wgrad_body<6>(jb, lb);
     else embed1_wgrad_body<14>(jb, lb);
@@ -45,12 +47,12 @@ __device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
-// Grouped launch: one job per (X, D) pair, ONE WAVE per 256-row chunk of a job (64-thread blocks; waves never talk to
-// each other).  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
+// Grouped launch: one job per (X, D) pair, ONE WAVE per 256-row chunk of a job; the four waves of a block take four
+// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 1,024 rows.  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
 // straight from global memory, every row read exactly once as whole 256-B lines: lane (m, g) loads the float4 at columns
 // 4m..4m+3 of row 4*step+g of X and of D; component va of the X load and component vb of the D load feed accumulator
 // (va, vb), so two loads feed 16 MFMAs.  No LDS, no barriers; loads run one 16-row batch ahead of the MFMAs.
-// Per-chunk partial slab [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
+// Per-block partial slab [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
 // ---------------------------------------------------------------------------------------------------------------
 #define WG_ROWS 256
 #define WG_SLAB (EMB * EMB + 2 * EMB)
@@ -81,7 +83,7 @@ __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, i
 }
 
 template <int EXTRA>
-__device__ __forceinline__ void wg_body(const WgJob& jb, float* __restrict__ slab, int rbeg, int rend) {
+__device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, int rend) {   // slab: this wave's LDS region
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4, col = 4 * m;
     f32x4w acc[4][4];
 #pragma unroll
@@ -127,7 +129,8 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* __restrict__ sla
     }
 }
 
-__global__ __launch_bounds__(64) void k_wgrad(WgArgs a, Emb1Args e) {
+__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e) {
+    extern __shared__ __attribute__((aligned(16))) float wg_red[];   // [WG_WAVES][WG_SLAB]
     if ((int)blockIdx.x >= a.nblocks) {   // the (short) first-embedding-layer chunks come after the long MFMA chunks
         embed1_wgrad_block(e, blockIdx.x - a.nblocks);
         return;
@@ -135,13 +138,22 @@ __global__ __launch_bounds__(64) void k_wgrad(WgArgs a, Emb1Args e) {
     int ji = 0;
     while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
     const WgJob jb = a.job[ji];
-    const int lb = blockIdx.x - jb.blk0;
-    const int rbeg = lb * WG_ROWS, rend = min(jb.n, rbeg + WG_ROWS);
-    float* slab = a.partial + (size_t)(jb.slab0 + lb) * WG_SLAB;
-    if (jb.seg_ptr) wg_body<1>(jb, slab, rbeg, rend);
-    else if (jb.d2) wg_body<2>(jb, slab, rbeg, rend);
-    else wg_body<0>(jb, slab, rbeg, rend);
+    const int lb = blockIdx.x - jb.blk0, wv = threadIdx.x >> 6;
+    const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * WG_ROWS), rend = min(jb.n, rbeg + WG_ROWS);   // may be empty: zeros
+    float* mine = wg_red + wv * WG_SLAB;
+    if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);
+    else if (jb.d2) wg_body<2>(jb, mine, rbeg, rend);
+    else wg_body<0>(jb, mine, rbeg, rend);
+    __syncthreads();
+    float4* slab = (float4*)(a.partial + (size_t)(jb.slab0 + lb) * WG_SLAB);
+    for (int i = threadIdx.x; i < WG_SLAB / 4; i += 64 * WG_WAVES) {
+        const float4 p0 = ((const float4*)wg_red)[i], p1 = ((const float4*)(wg_red + WG_SLAB))[i];
+        const float4 p2 = ((const float4*)(wg_red + 2 * WG_SLAB))[i], p3 = ((const float4*)(wg_red + 3 * WG_SLAB))[i];
+        slab[i] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                              (p0.w + p1.w) + (p2.w + p3.w));
+    }
 }
+static_assert(WG_WAVES == 4, "the block-level sum above is written for four waves");
 
 // Fixed-order sum of partial slabs into the flat gradient buffer.  One block per (job, 64-float chunk).
 #define RD_MAX_JOBS 96

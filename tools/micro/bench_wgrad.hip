@@ -31,18 +31,19 @@ int main() {
         {"3 plain 32k", 3, {32000, 32000, 32000}, {0, 0, 0}},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (auto& c : cfgs) {
         WgArgs a; a.njobs = c.njobs; a.partial = partial; int blk = 0;
         for (int j = 0; j < c.njobs; ++j) {
             a.job[j] = WgJob{x + (size_t)j * NMAX * 64, j == 1 ? sx : nullptr, d + (size_t)j * NMAX * 64, c.extra[j] == 1 ? seg : nullptr,
                              c.extra[j] == 2 ? q : nullptr, c.n[j], blk, blk};
-            blk += cdiv(c.n[j], WG_ROWS);
+            blk += cdiv(c.n[j], WG_ROWS * WG_WAVES);
         }
         a.nblocks = blk;
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64), 0, 0, a, Emb1Args{});
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{});
         CK(hipEventRecord(e0, 0));
         const int R = 50;
-        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64), 0, 0, a, Emb1Args{});
+        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{});
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-20s blocks %4d  %.2f us/launch\n", c.name, blk, ms * 1000 / R);
