@@ -1,0 +1,80 @@
+"""Data parallelism on the GPU with two real ranks: each rank takes its shard of the samples
+(`parallel.shard_samples`), back-propagates the local SUM of squared errors, the flat [gradients | cut count] buffer is
+all-reduced once, and gradient / count must equal the single-process gradient of the mean loss over ALL cuts of the global
+batch (model_trainer.py:271) -- also when the ranks hold different numbers of cuts.  Both ranks share the one GPU of the
+test box, so the collective runs over gloo (RCCL refuses two ranks on one device); the code path in `train_step` is the same."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gcnn_cut_selector_amd import synthetic  # noqa: E402
+from oracle import gcnn_oracle as O  # noqa: E402  (checker only)
+
+N_SAMPLES = 7
+
+
+def _samples():
+    return [synthetic.make_sample("combauc", i) for i in range(4)] + [synthetic.make_sample("setcov", i, scale=0.1) for i in range(3)]
+
+
+def _weights():
+    return O.randomize_params(O.init_params(11, np.float32), 12)
+
+
+def _worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    from gcnn_cut_selector_amd.model import GCNN
+    from gcnn_cut_selector_amd.parallel import shard_samples
+    from gcnn_cut_selector_amd.store import SampleStore
+    from gcnn_cut_selector_amd.trainer import TrainState, train_step
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    samples = _samples()
+    params = _weights()
+    m = GCNN(device=dev)
+    m.set_weights([params[n] for n in O.PARAM_NAMES])
+    sizes = [s[0][1]["indices"].shape[1] + s[0][4]["indices"].shape[1] for s in samples]
+    mine = shard_samples(sizes, world)[rank]
+    store = SampleStore.from_samples(samples, dev)
+    sb = store.batch(mine)
+    ts = TrainState(m)
+    train_step(m, sb.batch, sb.improvements, None, ts, process_group=dist.group.WORLD)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out_path, buf=ts.buf.cpu().numpy(), mine=np.asarray(mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_single_process_gradient(tmp_path):
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import torch.multiprocessing as mp
+    from gcnn_cut_selector_amd.model import GCNN
+    from gcnn_cut_selector_amd.store import SampleStore
+    from gcnn_cut_selector_amd.trainer import TrainState, train_step
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    # single process, whole batch, mean loss
+    dev = torch.device("cuda", 0)
+    samples, params = _samples(), _weights()
+    m = GCNN(device=dev)
+    m.set_weights([params[n] for n in O.PARAM_NAMES])
+    sb = SampleStore.from_samples(samples, dev).batch(np.arange(N_SAMPLES))
+    ts = TrainState(m)
+    train_step(m, sb.batch, sb.improvements, None, ts)
+    want = ts.grads.cpu().numpy()
+    n = want.size
+    count = got["buf"][n]
+    assert count == sb.batch.dims.n_cuts                      # the reduced count slot = cuts of the GLOBAL batch
+    assert 0 < len(got["mine"]) < N_SAMPLES                    # rank 0 really held only a shard
+    np.testing.assert_allclose(got["buf"][:n] / count, want, rtol=2e-4, atol=2e-6 * np.abs(want).max())
