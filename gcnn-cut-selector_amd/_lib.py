@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch shi
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
 LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GcnnError(RuntimeError):
@@ -62,7 +62,8 @@ SIGNATURES = {
     "gcnn_workspace_floats": (_Z, [_DP]),
     "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _I, _P]),
     "gcnn_mse_loss": (C.c_int, [_P, _P, _I, _F, _P, _P, _P]),
-    "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P, _P]),
+    "gcnn_forward_loss": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _F, _P]),
+    "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P, _P, _P]),
     "gcnn_prenorm_stats": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _I, _P, _P]),
     "gcnn_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _I, _P]),
     "gcnn_ranking_metric": (C.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P]),

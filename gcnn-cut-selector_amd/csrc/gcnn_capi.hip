@@ -140,13 +140,13 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
     w->stat_ids = (int*)take((size_t)std::max(d->n_cons_edges, d->n_cut_edges));
     w->score_nblk = cdiv(d->n_cuts, SB_ROWS);
-    w->score_partial = take((size_t)w->score_nblk * 2 * EMB);
+    w->score_partial = take((size_t)cdiv(d->n_cuts, 16) * HEAD_SLAB);   // per 64-cut block (k_score_bwd) or per tile (CF_LOSS)
     w->total = off;
 }
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 4; }
+int gcnn_abi_version(void) { return 5; }
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -393,14 +393,15 @@ static int launch_embed_fwd(EmbGroupArgs& m, hipStream_t st) {
     ROWS_LAUNCH(k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3], EMB_LDS_FLOATS * sizeof(float), st, m);
     return 0;
 }
-static int launch_conv_fwd(const ConvFArgs& a, bool readout, hipStream_t st) {
+static int launch_conv_fwd(const ConvFArgs& a, int tail, hipStream_t st) {
     int blk0[2];
     const int ns = 4;
     const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
     if (blk0[1] == 0) return 0;
     const size_t smem = ROWS_LDS_FLOATS(5, 5) * sizeof(float);
-    if (readout) ROWS_LAUNCH((k_conv_fwd<8, true>), (k_conv_fwd<4, true>), nwaves, blk0[1], smem, st, a);
-    else ROWS_LAUNCH((k_conv_fwd<8, false>), (k_conv_fwd<4, false>), nwaves, blk0[1], smem, st, a);
+    if (tail == CF_LOSS) ROWS_LAUNCH((k_conv_fwd<8, CF_LOSS>), (k_conv_fwd<4, CF_LOSS>), nwaves, blk0[1], smem, st, a);
+    else if (tail == CF_READOUT) ROWS_LAUNCH((k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
+    else ROWS_LAUNCH((k_conv_fwd<8, CF_PROJ>), (k_conv_fwd<4, CF_PROJ>), nwaves, blk0[1], smem, st, a);
     return 0;
 }
 static int launch_conv_bwd(ConvBGroupArgs& m, hipStream_t st) {
@@ -441,8 +442,9 @@ static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
 
 // edge pass + the receiver-side update program S -> A -> Z1 -> X' (model.py:498-508, 568-573) and, in the same launch, what
 // consumes X': the next convolution's projection (wt, bt -> t_out) or the readout
+struct LossHead { const float* targets; float scale; float* g_o1; float* partial; };   // CF_LOSS extras
 static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, const float* wt, const float* bt,
-                        float* t_out, bool readout, float* scores) {
+                        float* t_out, int tail, float* scores, const LossHead* head) {
     int rc;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
     e.out = c.S; e.mask = c.mask; e.cnt_rows = c.N;
@@ -455,8 +457,9 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
     a.z1 = save ? c.Z1 : nullptr;
     a.w2 = p + poff(c.pbase + C_W2); a.b2 = p + poff(c.pbase + C_B2); a.out = c.OUT;
     a.wt = wt; a.bt = bt; a.t_out = t_out;
-    if (readout) { a.ws = p + poff(P_OUT + 2); a.bs = p + poff(P_OUT + 3); a.scores = scores; }
-    return launch_conv_fwd(a, readout, st);
+    if (tail != CF_PROJ) { a.ws = p + poff(P_OUT + 2); a.bs = p + poff(P_OUT + 3); a.scores = scores; }
+    if (tail == CF_LOSS) { a.targets = head->targets; a.loss_scale = head->scale; a.g_o1 = head->g_o1; a.head_partial = head->partial; }
+    return launch_conv_fwd(a, tail, st);
 }
 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
@@ -478,15 +481,15 @@ static int check_common(const gcnn_dims* d, const float* params, const gcnn_grap
     return 0;
 }
 
-extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
-                 const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
-                 size_t workspace_floats, float* scores, int32_t save_for_backward, void* stream) {
+// `targets` != nullptr: the last launch also evaluates the MSE head and the readout's Dense(64->1) gradient (CF_LOSS)
+static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                        const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                        size_t workspace_floats, float* scores, bool save, const float* targets, float loss_scale,
+                        hipStream_t st) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
     if (d->n_cuts > 0 && !scores) return GCNN_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    const bool save = save_for_backward != 0;
     Work w; carve(d, workspace, &w);
     const Acts& A = w.a;
     // embeddings (model.py:287-291) fused with the projections of the raw embeddings they feed (model.py:486-496): three
@@ -509,13 +512,30 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     // updated constraints -> left projection of conv c->v
-    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, false, nullptr))) return rc;
+    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, CF_PROJ, nullptr, nullptr))) return rc;
     // updated variables -> right projection of conv v->k
-    if ((rc = conv_forward(p, cv[1], save, st, p + poff(P_CONV2 + C_WR), nullptr, A.PR3, false, nullptr))) return rc;
+    if ((rc = conv_forward(p, cv[1], save, st, p + poff(P_CONV2 + C_WR), nullptr, A.PR3, CF_PROJ, nullptr, nullptr))) return rc;
     // updated cuts -> readout (model.py:206-208, 299-300)
-    if ((rc = conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), save ? A.O1 : nullptr, true, scores))) return rc;
-    return 0;
+    if (targets) {   // O1 itself is not needed afterwards: its ReLU mask is folded into dO1pre, its values into the dws partials
+        const LossHead head = {targets, loss_scale, w.g.O1, w.score_partial};
+        return conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), nullptr, CF_LOSS, scores, &head);
+    }
+    return conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), save ? A.O1 : nullptr, CF_READOUT, scores, nullptr);
 }
+extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                 const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                 size_t workspace_floats, float* scores, int32_t save_for_backward, void* stream) {
+    return forward_impl(d, p, cons_feats, var_feats, cut_feats, cg, kg, workspace, workspace_floats, scores,
+                        save_for_backward != 0, nullptr, 0.f, (hipStream_t)stream);
+}
+extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
+                      const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
+                      size_t workspace_floats, float* scores, const float* targets, float loss_scale, void* stream) {
+    if (d && d->n_cuts > 0 && !targets) return GCNN_E_BADARG;
+    return forward_impl(d, p, cons_feats, var_feats, cut_feats, cg, kg, workspace, workspace_floats, scores, true,
+                        d && d->n_cuts > 0 ? targets : nullptr, loss_scale, (hipStream_t)stream);
+}
+
 
 // ---- backward ---------------------------------------------------------------------------------------------------
 struct JobList {
@@ -598,12 +618,16 @@ extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t 
 
 extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
-                  size_t workspace_floats, const float* d_scores, float* grads, float* cut_count_out, void* stream) {
+                  size_t workspace_floats, const float* d_scores, float* grads, float* cut_count_out, float* loss_out,
+                  void* stream) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
-    if (!grads || (d->n_cuts > 0 && !d_scores)) return GCNN_E_BADARG;
-    // data-parallel callers all-reduce [gradients | cut count]: the count is stored by the first backward kernel
+    if (!grads) return GCNN_E_BADARG;
+    // d_scores == NULL: the loss head already ran inside gcnn_forward_loss (dO1pre and its partials are in the workspace)
+    const bool fused_head = d_scores == nullptr;
+    if (loss_out && (!fused_head || d->n_cuts <= 0)) HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+    // data-parallel callers all-reduce [gradients | cut count]: the count is stored by a backward kernel
     if (cut_count_out && d->n_cuts <= 0) HIPCHK(hipMemsetAsync(cut_count_out, 0, sizeof(float), (hipStream_t)stream));
     hipStream_t st = (hipStream_t)stream;
     Work w; carve(d, workspace, &w);
@@ -619,11 +643,18 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
         {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
     // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
-    hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
-                       w.score_partial, cut_count_out, d->n_cuts);
-    LAUNCHCHK();
-    add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), w.score_nblk, 2 * EMB, EMB);
-    add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), w.score_nblk, 2 * EMB, 1);
+    int head_parts = w.score_nblk;
+    if (fused_head) {
+        head_parts = cdiv(d->n_cuts, 16);   // one partial per tile of the readout program
+        if (loss_out) add_rd(jl, w.score_partial + EMB + 1, loss_out, head_parts, HEAD_SLAB, 1);
+        jl.rd.cdst = cut_count_out; jl.rd.cval = (float)d->n_cuts;
+    } else {
+        hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
+                           w.score_partial, cut_count_out, d->n_cuts);
+        LAUNCHCHK();
+    }
+    add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), head_parts, HEAD_SLAB, EMB);
+    add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), head_parts, HEAD_SLAB, 1);
     add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
     auto tail = [&](TailBArgs& t, const float* in_a, const float* wa, const float* in_b, const float* wb, float* gx, const float* x,
                     int pb, float* ge1, int n) {

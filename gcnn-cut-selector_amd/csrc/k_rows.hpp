@@ -253,18 +253,33 @@ __global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
 //   A  = S Wf + deg_r bf                 (the per-edge Dense hoisted past the scatter-sum)        -> a_out (optional)
 //   Z1 = relu([s2*A | x_recv] W1 + b1)                                                             -> z1 (optional)
 //   X' = relu(Z1 W2 + b2)                                                                          -> out
-//   READOUT = false:  T = X' Wt (+ bt): the next convolution's projection                          -> t_out
-//   READOUT = true :  O1 = relu(X' Wt + bt) -> o1 (optional);  score = O1 . ws + bs (model.py:206-208) -> scores
+//   TAIL = CF_PROJ   :  T = X' Wt (+ bt): the next convolution's projection                        -> t_out
+//   TAIL = CF_READOUT:  O1 = relu(X' Wt + bt) -> o1 (optional);  score = O1 . ws + bs (model.py:206-208) -> scores
+//   TAIL = CF_LOSS   :  the readout and, in the same pass, the MSE head (model_trainer.py:271) and the gradient of the
+//                       readout's Dense(64->1): with d_k = score_k - y_k,  ds_k = 2*scale*d_k,
+//                         dO1pre[k] = ds_k * ws * (O1[k] > 0)                                       -> g_o1
+//                         per-tile partials {dws = sum_k ds_k O1[k], dbs = sum_k ds_k, loss = scale*sum_k d_k^2} -> head_partial
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvFArgs {
     const float* s; const int* seg_ptr; const float *wf, *bf; float* a_out;
     const float *s2, *xrecv, *w1a, *w1b, *b1; float* z1;
     const float *w2, *b2; float* out;
-    const float *wt, *bt; float* t_out;      // READOUT: wt/bt = readout Dense(64,relu), t_out = O1
-    const float *ws, *bs; float* scores;      // READOUT only
+    const float *wt, *bt; float* t_out;      // readout: wt/bt = readout Dense(64,relu), t_out = O1
+    const float *ws, *bs; float* scores;      // readout only
+    const float* targets; float loss_scale; float* g_o1; float* head_partial;   // CF_LOSS only; partial: [tiles][HEAD_SLAB]
     int n;
 };
-template <bool READOUT, int NT>
+enum { CF_PROJ = 0, CF_READOUT = 1, CF_LOSS = 2 };
+#define HEAD_SLAB (2 * EMB)   // per-tile partial of the loss head: dws[64], dbs at 64, loss at 65
+// sum over the 16 lanes of a DPP row (= the 16 rows of a tile), result in every lane of the row
+__device__ __forceinline__ float row_sum16(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));  // row_ror:1
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));  // row_ror:2
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));  // row_ror:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
+    return x;
+}
+template <int TAIL, int NT>
 __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, int bid, int nblk) {
     constexpr int NWAVES = NT / 64, NM = 5, NV = 5;   // Wf W1a W1b W2 Wt | bf b1 b2 bt ws
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
@@ -283,11 +298,11 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
     load_ops(tile);
     {
         const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
-        const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, READOUT ? a.ws : nullptr};
+        const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, TAIL != CF_PROJ ? a.ws : nullptr};
         stage_lds<5, 5, NT>(smem, w, v);
     }
     const float s2 = *a.s2;
-    const float bs = READOUT ? *a.bs : 0.f;
+    const float bs = TAIL != CF_PROJ ? *a.bs : 0.f;
     __syncthreads();
     for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
         if (!first) load_ops(tile);
@@ -316,7 +331,7 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
         rt_clear_unless(t0, ok);
         rt_store(t0, a.out, row, ok, g);
         rt_mm<false>(t1, t0, 1.f, smem + 4 * 64 * LDW, lane);
-        if (!READOUT) {
+        if (TAIL == CF_PROJ) {
             rt_bias<false>(t1, vecs + 3 * 64, g);
             rt_store(t1, a.t_out, row, ok, g);
         } else {
@@ -331,14 +346,36 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
                 sum = fmaf(t1.v[m][0], w.x, fmaf(t1.v[m][1], w.y, fmaf(t1.v[m][2], w.z, fmaf(t1.v[m][3], w.w, sum))));
             }
             sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-            if (g == 0 && ok) a.scores[row] = sum + bs;
+            const float score = sum + bs;
+            if (g == 0 && ok) a.scores[row] = score;
+            if (TAIL == CF_LOSS) {
+                const float dlt = ok ? score - a.targets[row] : 0.f;
+                const float ds = 2.f * dlt * a.loss_scale;
+                RTile go;
+                float* slab = a.head_partial + (size_t)tile * HEAD_SLAB;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 w = *(const float4*)(wsv + 16 * m + 4 * g);
+                    const float wv4[4] = {w.x, w.y, w.z, w.w};
+                    float cs[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        go.v[m][i] = t1.v[m][i] > 0.f ? ds * wv4[i] : 0.f;
+                        cs[i] = row_sum16(ds * t1.v[m][i]);
+                    }
+                    if (j == 0) *(float4*)(slab + 16 * m + 4 * g) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                }
+                rt_store(go, a.g_o1, row, ok, g);
+                const float dbs = row_sum16(ds), ls = row_sum16(a.loss_scale * dlt * dlt);
+                if (lane == 0) { slab[EMB] = dbs; slab[EMB + 1] = ls; }
+            }
         }
     }
 }
-template <int NWAVES, bool READOUT>
+template <int NWAVES, int TAIL>
 __global__ __launch_bounds__(NWAVES * 64) void k_conv_fwd(ConvFArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    convf_program<READOUT, NWAVES * 64>(a, smem, blockIdx.x, gridDim.x);
+    convf_program<TAIL, NWAVES * 64>(a, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

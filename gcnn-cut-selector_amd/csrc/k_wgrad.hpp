@@ -158,10 +158,11 @@ static_assert(WG_WAVES == 4, "the block-level sum above is written for four wave
 // Fixed-order sum of partial slabs into the flat gradient buffer.  One block per (job, 64-float chunk).
 #define RD_MAX_JOBS 96
 struct RdJob { const float* src; float* dst; int nparts; int stride; int len; int blk0; };
-struct RdArgs { int njobs; RdJob job[RD_MAX_JOBS]; };
+struct RdArgs { int njobs; float* cdst; float cval; RdJob job[RD_MAX_JOBS]; };   // cdst (optional): a constant the launch also stores
 
 __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
     __shared__ float red[4][EMB];
+    if (a.cdst && blockIdx.x == 0 && threadIdx.x == 0) *a.cdst = a.cval;
     int ji = 0;
     while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
     const RdJob jb = a.job[ji];

@@ -320,12 +320,24 @@ class GCNN:
                                                int(save), _stream(self.device)), "gcnn_forward")
         return scores
 
-    def _backward_into(self, flat, batch, ws, d_scores, grads, count_slot=None):
+    def _forward_loss_into(self, flat, batch, ws, targets, loss_scale):
+        """Forward with the MSE head fused into its last launch (gcnn_forward_loss); continue with
+        `_backward_into(d_scores=None, ..., loss_out=...)`."""
+        scores = torch.empty(batch.dims.n_cuts, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().gcnn_forward_loss(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
+                                                    _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
+                                                    C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(scores),
+                                                    _ptr(targets), float(loss_scale), _stream(self.device)), "gcnn_forward_loss")
+        return scores
+
+    def _backward_into(self, flat, batch, ws, d_scores, grads, count_slot=None, loss_out=None):
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().gcnn_backward(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
                                                 _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
                                                 C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(d_scores),
-                                                _ptr(grads), _ptr(count_slot), _stream(self.device)), "gcnn_backward")
+                                                _ptr(grads), _ptr(count_slot), _ptr(loss_out), _stream(self.device)),
+                       "gcnn_backward")
 
     def call(self, inputs, training=False):
         """GCNN.call (model.py:257-300): flat fp32 scores, one per candidate cut.  `training` is accepted and ignored

@@ -111,18 +111,23 @@ def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam
     and Adam divides by the global cut count -- the mean over ALL cuts of the global batch, not a mean of per-rank means."""
     flat = model.flat_parameters.detach()
     ws = model._take_workspace(batch)
-    scores = model._forward_into(flat, batch, ws)
     n_cuts = batch.dims.n_cuts
+    if targets.dtype != torch.float32 or not targets.is_contiguous():
+        targets = targets.to(torch.float32).contiguous()
+    if targets.numel() != n_cuts:
+        raise ValueError(f"expected {n_cuts} targets, got {targets.numel()}")
+    loss = torch.empty(1, dtype=torch.float32, device=model.device)
+    # The MSE head rides in the forward's last launch (gcnn_forward_loss), so the backward starts at the readout's hidden layer
     if process_group is None:
-        loss, d_scores = mse_loss(scores, targets, 1.0 / max(n_cuts, 1))
-        model._backward_into(flat, batch, ws, d_scores, state.grads)
+        scores = model._forward_loss_into(flat, batch, ws, targets, 1.0 / max(n_cuts, 1))
+        model._backward_into(flat, batch, ws, None, state.grads, loss_out=loss)
         model._give_workspace(ws)
         if optimizer is not None:
             (optimizer.apply_flat_dev if device_optimizer else optimizer.apply_flat)(model, state.grads)
         return loss, scores
     import torch.distributed as dist
-    loss, d_scores = mse_loss(scores, targets, 1.0)  # local SUM of squared errors
-    model._backward_into(flat, batch, ws, d_scores, state.grads, count_slot=state.count)  # also stores the local cut count
+    scores = model._forward_loss_into(flat, batch, ws, targets, 1.0)   # local SUM of squared errors
+    model._backward_into(flat, batch, ws, None, state.grads, count_slot=state.count, loss_out=loss)  # also stores the local cut count
     model._give_workspace(ws)
     dist.all_reduce(state.buf, op=dist.ReduceOp.SUM, group=process_group)   # ONE collective: gradients + cut count
     if optimizer is not None:  # Adam divides by the global cut count: the mean over ALL cuts of the global batch

@@ -145,15 +145,27 @@ int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_f
 int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out,
                   float* d_scores, void* stream);
 
+/* ---- forward + loss head in one pass (the training step's forward, model_trainer.py:269-271) -------------------
+ * As gcnn_forward(save_for_backward = 1); the last launch also evaluates the MSE head on its own scores,
+ *   loss = loss_scale * sum_k (score_k - targets_k)^2    (loss_scale = 1/n_cuts: Keras' mean),
+ * and the gradient of the readout's Dense(64->1) w.r.t. that loss, leaving both in the workspace: follow with
+ * gcnn_backward(d_scores = NULL, ..., loss_out).  Saves the separate gcnn_mse_loss launch and the first backward launch. */
+int gcnn_forward_loss(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
+                      const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
+                      float* workspace, size_t workspace_floats, float* scores, const float* targets,
+                      float loss_scale, void* stream);
+
 /* ---- backward: the vector-Jacobian product tf.GradientTape computes for GCNN.call, model_trainer.py:269-272 ----
- * d_scores: [n_cuts] gradient of the loss w.r.t. the scores.  Gradients w.r.t. the 46 trainable tensors are
- * written to `grads` (flat layout; non-trainable and padding slots are left untouched -- keep them zero).  Must follow
- * gcnn_forward on the same workspace, inputs and parameters. */
+ * d_scores: [n_cuts] gradient of the loss w.r.t. the scores; must follow gcnn_forward(save_for_backward = 1) on the same
+ * workspace, inputs and parameters.  d_scores = NULL: continue from gcnn_forward_loss instead (the loss head already ran);
+ * loss_out (optional) then receives that loss.  Gradients w.r.t. the 46 trainable tensors are written to `grads` (flat
+ * layout; non-trainable and padding slots are left untouched -- keep them zero). */
 int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
                   float* workspace, size_t workspace_floats, const float* d_scores, float* grads,
                   float* cut_count_out /* optional: receives (float)n_cuts, the slot data-parallel callers all-reduce
-                                          together with the gradients */, void* stream);
+                                          together with the gradients */,
+                  float* loss_out /* optional, see above */, void* stream);
 
 /* ---- PreNorm fitting statistics: PreNormLayer.update_params, model.py:394-423 -----------------------------------
  * For ONE batch and ONE of the 11 PreNorm layers (call order: 0 cons, 1 cons-edge, 2 var, 3 cut, 4 cut-edge, then
