@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch shi
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
 LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GcnnError(RuntimeError):
@@ -32,6 +32,11 @@ class Graph(C.Structure):
     _fields_ = [("l_ptr", C.c_void_p), ("l_oth", C.c_void_p), ("l_coef", C.c_void_p),
                 ("v_ptr", C.c_void_p), ("v_oth", C.c_void_p), ("v_coef", C.c_void_p),
                 ("l2v", C.c_void_p), ("v2l", C.c_void_p)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("lr_t", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float)]
 
 
 class CollateJob(C.Structure):
@@ -63,7 +68,7 @@ SIGNATURES = {
     "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _I, _P]),
     "gcnn_mse_loss": (C.c_int, [_P, _P, _I, _F, _P, _P, _P]),
     "gcnn_forward_loss": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _F, _P]),
-    "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P, _P, _P]),
+    "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P, _P, _P, _P]),
     "gcnn_prenorm_stats": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _I, _P, _P]),
     "gcnn_adam_step": (C.c_int, [_P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _I, _P]),
     "gcnn_ranking_metric": (C.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P]),

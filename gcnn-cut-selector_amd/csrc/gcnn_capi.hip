@@ -146,7 +146,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 5; }
+int gcnn_abi_version(void) { return 6; }
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -619,11 +619,17 @@ extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t 
 extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                   const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                   size_t workspace_floats, const float* d_scores, float* grads, float* cut_count_out, float* loss_out,
-                  void* stream) {
+                  const gcnn_adam_args* adam, void* stream) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
-    if (!grads) return GCNN_E_BADARG;
+    if (!grads || (adam && (!adam->params || !adam->m || !adam->v))) return GCNN_E_BADARG;
+    // The optimizer step rides in the reduction launch when that launch (re)writes every trainable gradient; otherwise
+    // (degenerate batches) it runs as its own launch at the end -- either way the caller gets backward + Adam.
+    auto adam_after = [&]() -> int {
+        return adam ? gcnn_adam_step(adam->params, grads, adam->m, adam->v, g_ptotal, adam->lr_t, adam->beta1, adam->beta2, adam->eps,
+                                     nullptr, 0, stream) : 0;
+    };
     // d_scores == NULL: the loss head already ran inside gcnn_forward_loss (dO1pre and its partials are in the workspace)
     const bool fused_head = d_scores == nullptr;
     if (loss_out && (!fused_head || d->n_cuts <= 0)) HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
@@ -636,7 +642,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
 
     // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
-    if (d->n_cuts <= 0) return 0;  // no cut => every gradient is 0
+    if (d->n_cuts <= 0) return adam_after();  // no cut => every gradient is 0
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
         {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
@@ -712,11 +718,13 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64 * WG_WAVES), smem, st, jl.wg, ea);
         LAUNCHCHK();
     }
+    const bool fuse_adam = adam && d->n_cons > 0 && d->n_vars > 0 && jl.rdblk > 0;
+    if (fuse_adam) jl.rd.adam = RdAdam{adam->params, adam->m, adam->v, grads, g_ptotal, adam->lr_t, adam->beta1, adam->beta2, adam->eps};
     if (jl.rdblk > 0) {
         hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
         LAUNCHCHK();
     }
-    return 0;
+    return fuse_adam ? 0 : adam_after();
 }
 
 // ---- PreNorm fitting statistics (model.py:394-423) ------------------------------------------------------------------

@@ -158,7 +158,10 @@ static_assert(WG_WAVES == 4, "the block-level sum above is written for four wave
 // Fixed-order sum of partial slabs into the flat gradient buffer.  One block per (job, 64-float chunk).
 #define RD_MAX_JOBS 96
 struct RdJob { const float* src; float* dst; int nparts; int stride; int len; int blk0; };
-struct RdArgs { int njobs; float* cdst; float cval; RdJob job[RD_MAX_JOBS]; };   // cdst (optional): a constant the launch also stores
+// optional fused optimizer step: every reduced element that lies inside the flat gradient buffer [gbase, gbase+gn) is a
+// finished gradient, so the Keras-form Adam update (see k_adam) of the same flat slot can follow in the same thread
+struct RdAdam { float* p; float* m; float* v; const float* gbase; int gn; float lr_t, b1, b2, eps; };
+struct RdArgs { int njobs; float* cdst; float cval; RdAdam adam; RdJob job[RD_MAX_JOBS]; };   // cdst (optional): a constant the launch also stores
 
 __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
     __shared__ float red[4][EMB];
@@ -182,6 +185,16 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
     }
     red[part][col] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (part == 0 && e < jb.len) jb.dst[e] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (part == 0 && e < jb.len) {
+        const float gi = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        jb.dst[e] = gi;
+        const long long idx = (jb.dst + e) - a.adam.gbase;
+        if (a.adam.p && idx >= 0 && idx < a.adam.gn) {
+            const float mi = a.adam.b1 * a.adam.m[idx] + (1.f - a.adam.b1) * gi;
+            const float vi = a.adam.b2 * a.adam.v[idx] + (1.f - a.adam.b2) * gi * gi;
+            a.adam.m[idx] = mi; a.adam.v[idx] = vi;
+            a.adam.p[idx] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+        }
+    }
 }
 

@@ -331,12 +331,14 @@ class GCNN:
                                                     _ptr(targets), float(loss_scale), _stream(self.device)), "gcnn_forward_loss")
         return scores
 
-    def _backward_into(self, flat, batch, ws, d_scores, grads, count_slot=None, loss_out=None):
+    def _backward_into(self, flat, batch, ws, d_scores, grads, count_slot=None, loss_out=None, adam=None):
+        """`adam`: optional `_lib.AdamArgs` -- the optimizer step then rides in the backward's last launch."""
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().gcnn_backward(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),
                                                 _ptr(batch.var_feats), _ptr(batch.cut_feats), C.byref(batch.cons_graph.c),
                                                 C.byref(batch.cut_graph.c), _ptr(ws), ws.numel(), _ptr(d_scores),
-                                                _ptr(grads), _ptr(count_slot), _ptr(loss_out), _stream(self.device)),
+                                                _ptr(grads), _ptr(count_slot), _ptr(loss_out),
+                                                C.byref(adam) if adam is not None else None, _stream(self.device)),
                        "gcnn_backward")
 
     def call(self, inputs, training=False):

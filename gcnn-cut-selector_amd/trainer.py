@@ -62,6 +62,17 @@ class Adam:
                                                  lr_t, self.beta_1, self.beta_2, self.epsilon, _ptr(grad_scale),
                                                  int(divide), _stream(flat.device)), "gcnn_adam_step")
 
+    def fused_args(self, model: GCNN):
+        """Advance the step counter and return the `gcnn_adam_args` for `GCNN._backward_into(adam=...)`: the same update as
+        `apply_flat`, executed by the backward pass's last launch instead of a launch of its own."""
+        flat = model.flat_parameters.detach()
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self._lr() * math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        return _lib.AdamArgs(flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), lr_t, self.beta_1, self.beta_2, self.epsilon)
+
     def apply_flat_dev(self, model: GCNN, flat_grad: torch.Tensor, grad_scale: torch.Tensor | None = None, divide=False):
         """The same update with hyper-parameters and step counter resident on the device (gcnn_adam_step_dev): nothing
         step-dependent crosses the host, so the call can sit inside a captured hipGraph and be replayed."""
@@ -120,10 +131,11 @@ def train_step(model: GCNN, batch: Batch, targets: torch.Tensor, optimizer: Adam
     # The MSE head rides in the forward's last launch (gcnn_forward_loss), so the backward starts at the readout's hidden layer
     if process_group is None:
         scores = model._forward_loss_into(flat, batch, ws, targets, 1.0 / max(n_cuts, 1))
-        model._backward_into(flat, batch, ws, None, state.grads, loss_out=loss)
+        fuse = optimizer is not None and not device_optimizer   # host-parameterised Adam: rides in the backward's last launch
+        model._backward_into(flat, batch, ws, None, state.grads, loss_out=loss, adam=optimizer.fused_args(model) if fuse else None)
         model._give_workspace(ws)
-        if optimizer is not None:
-            (optimizer.apply_flat_dev if device_optimizer else optimizer.apply_flat)(model, state.grads)
+        if optimizer is not None and not fuse:
+            optimizer.apply_flat_dev(model, state.grads)
         return loss, scores
     import torch.distributed as dist
     scores = model._forward_loss_into(flat, batch, ws, targets, 1.0)   # local SUM of squared errors

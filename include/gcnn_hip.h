@@ -145,6 +145,12 @@ int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_f
 int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out,
                   float* d_scores, void* stream);
 
+/* Keras-form Adam step (see gcnn_adam_step) to run right behind a backward pass. */
+typedef struct gcnn_adam_args {
+    float* params; float* m; float* v;   /* flat buffers, gcnn_param_total_floats() each; params is updated in place */
+    float lr_t, beta1, beta2, eps;
+} gcnn_adam_args;
+
 /* ---- forward + loss head in one pass (the training step's forward, model_trainer.py:269-271) -------------------
  * As gcnn_forward(save_for_backward = 1); the last launch also evaluates the MSE head on its own scores,
  *   loss = loss_scale * sum_k (score_k - targets_k)^2    (loss_scale = 1/n_cuts: Keras' mean),
@@ -165,7 +171,9 @@ int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_
                   float* workspace, size_t workspace_floats, const float* d_scores, float* grads,
                   float* cut_count_out /* optional: receives (float)n_cuts, the slot data-parallel callers all-reduce
                                           together with the gradients */,
-                  float* loss_out /* optional, see above */, void* stream);
+                  float* loss_out /* optional, see above */,
+                  const gcnn_adam_args* adam /* optional: apply gcnn_adam_step(params, grads, ...) right behind, fused into the
+                                                last launch whenever the gradients allow it */, void* stream);
 
 /* ---- PreNorm fitting statistics: PreNormLayer.update_params, model.py:394-423 -----------------------------------
  * For ONE batch and ONE of the 11 PreNorm layers (call order: 0 cons, 1 cons-edge, 2 var, 3 cut, 4 cut-edge, then
