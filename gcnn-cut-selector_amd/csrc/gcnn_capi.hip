@@ -134,7 +134,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
-        w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS);
+        w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS * WG_WAVES);   // blocks = slabs
         w->emb_partial[i] = take((size_t)w->emb_nblk[i] * (femb[i] + 1) * EMB);
     }
     w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
@@ -702,8 +702,8 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     for (int i = 0; i < 3; ++i) {
         if (em[i].n <= 0) continue;
         ea.job[ea.njobs++] = Emb1Job{em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1,
-                                     w.emb_partial[i], em[i].n, em[i].f, ea.nblocks, w.emb_nblk[i]};
-        ea.nblocks += cdiv(w.emb_nblk[i], WG_WAVES);
+                                     w.emb_partial[i], em[i].n, em[i].f, ea.nblocks};
+        ea.nblocks += w.emb_nblk[i];
         // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
         add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
         add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);

@@ -6,22 +6,22 @@
 // the forward embedding programs (emb_program in k_rows.hpp); here its weight gradient on the VALU (K = f <= 14).
 // ---------------------------------------------------------------------------------------------------------------
 // gradient of the first embedding layer's weights: dW[f][j] = sum_r xn[r][f] * dPre[r][j], db[j] = sum_r dPre[r][j]
-// with dPre = dY * (Y > 0).  One WAVE per chunk of EMB1_ROWS rows, lane = output column; per-chunk partial slab
-// [(F+1)*64] (row F = bias).  The three embeddings (F = 4, 14, 6) are extra block ranges of the k_wgrad launch below.
+// with dPre = dY * (Y > 0).  One WAVE per chunk of EMB1_ROWS rows, lane = output column; the four waves of a block add up
+// in LDS: per-block partial slab [(F+1)*64] (row F = bias).  The three embeddings (F = 4, 14, 6) are extra block ranges of the k_wgrad launch below.
 #define EMB1_ROWS 64
 #define WG_WAVES 4    // waves (= chunks) per block of the k_wgrad launch
-struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; int nchunk; };
+struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; };
 struct Emb1Args { int njobs; int nblocks; Emb1Job job[3]; };
 
 template <int F>
-__device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int lb) {
-    const int col = threadIdx.x & 63;
+__device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int blk, float* red) {
+    const int col = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float acc[F + 1], shift[F], scale[F];
 #pragma unroll
     for (int f = 0; f <= F; ++f) acc[f] = 0.f;
 #pragma unroll
     for (int f = 0; f < F; ++f) { shift[f] = jb.shift[f]; scale[f] = jb.scale[f]; }
-    const int r0 = lb * EMB1_ROWS;
+    const int r0 = min(jb.n, (blk * WG_WAVES + wv) * EMB1_ROWS);   // this wave's chunk (may be empty: zeros)
     const int r1 = min(jb.n, r0 + EMB1_ROWS);
 #pragma unroll 8
     for (int r = r0; r < r1; ++r) {
@@ -31,18 +31,21 @@ __device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int lb) {
         for (int f = 0; f < F; ++f) acc[f] = fmaf((jb.x[(size_t)r * F + f] + shift[f]) * scale[f], d, acc[f]);   // x: wave-uniform
         acc[F] += d;
     }
+    // the four waves of the block add up in LDS: one partial slab per block
 #pragma unroll
-    for (int f = 0; f <= F; ++f) jb.partial[(size_t)lb * (F + 1) * EMB + f * EMB + col] = acc[f];
+    for (int f = 0; f <= F; ++f) red[wv * 15 * EMB + f * EMB + col] = acc[f];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (F + 1) * EMB; i += 64 * WG_WAVES)
+        jb.partial[(size_t)blk * (F + 1) * EMB + i] = (red[i] + red[15 * EMB + i]) + (red[2 * 15 * EMB + i] + red[3 * 15 * EMB + i]);
 }
-__device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b) {
+__device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b, float* red) {
     int ji = 0;
     while (ji + 1 < a.njobs && b >= a.job[ji + 1].blk0) ++ji;
     const Emb1Job jb = a.job[ji];
-    const int lb = (b - jb.blk0) * WG_WAVES + (threadIdx.x >> 6);   // this wave's chunk
-    if (lb >= jb.nchunk) return;
-    if (jb.f == 4) embed1_wgrad_body<4>(jb, lb);
-    else if (jb.f == 6) embed1_wgrad_body<6>(jb, lb);
-    else embed1_wgrad_body<14>(jb, lb);
+    const int blk = b - jb.blk0;
+    if (jb.f == 4) embed1_wgrad_body<4>(jb, blk, red);
+    else if (jb.f == 6) embed1_wgrad_body<6>(jb, blk, red);
+    else embed1_wgrad_body<14>(jb, blk, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -132,7 +135,7 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e) {
     extern __shared__ __attribute__((aligned(16))) float wg_red[];   // [WG_WAVES][WG_SLAB]
     if ((int)blockIdx.x >= a.nblocks) {   // the (short) first-embedding-layer chunks come after the long MFMA chunks
-        embed1_wgrad_block(e, blockIdx.x - a.nblocks);
+        embed1_wgrad_block(e, blockIdx.x - a.nblocks, wg_red);
         return;
     }
     int ji = 0;

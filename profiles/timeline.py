@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_adam")]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_reduce")]   # the last launch of a training step
 a, b = idx[-6], idx[-5]
 prev_end = int(rows[a]["End_Timestamp"])
 for r in rows[a + 1:b + 1]:
