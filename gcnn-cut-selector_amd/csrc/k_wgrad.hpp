@@ -50,14 +50,15 @@ __device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b, flo
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
-// Grouped launch: one job per (X, D) pair, ONE WAVE per 256-row chunk of a job; the four waves of a block take four
-// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 1,024 rows.  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
+// Grouped launch: one job per (X, D) pair, ONE WAVE per WG_ROWS-row chunk of a job; the four waves of a block take four
+// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 512 rows (128-row chunks
+// balance the 1,024 SIMDs better than 256-row ones; 64-row ones drown in prologue).  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
 // straight from global memory, every row read exactly once as whole 256-B lines: lane (m, g) loads the float4 at columns
 // 4m..4m+3 of row 4*step+g of X and of D; component va of the X load and component vb of the D load feed accumulator
-// (va, vb), so two loads feed 16 MFMAs.  No LDS, no barriers; loads run one 16-row batch ahead of the MFMAs.
+// (va, vb), so two loads feed 16 MFMAs.  No LDS or barriers in the main loop; loads run one 16-row batch ahead of the MFMAs.
 // Per-block partial slab [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
 // ---------------------------------------------------------------------------------------------------------------
-#define WG_ROWS 256
+#define WG_ROWS 128
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 24
 #define WG_STEPS 4   // 4-row MFMA steps per batch of loads
