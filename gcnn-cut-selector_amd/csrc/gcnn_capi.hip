@@ -546,7 +546,7 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
                    int n, float* gw, float* gb, float* g2, float* partial) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
     WgJob& j = jl.wg.job[jl.wg.njobs++];
-    const int nb = cdiv(n, WG_ROWS * WG_WAVES);   // blocks = slabs: four 256-row chunks each
+    const int nb = cdiv(n, jl.wg.rows_per_wave * WG_WAVES);   // blocks = slabs: four chunks each
     j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.d2 = d2; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
     const float* src = partial + (size_t)jl.nslab * WG_SLAB;
     jl.wg.nblocks += nb; jl.nslab += nb;
@@ -639,6 +639,11 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     Work w; carve(d, workspace, &w);
     const Acts &A = w.a, &G = w.g;
     JobList jl; memset(&jl, 0, sizeof(jl)); jl.wg.partial = w.partial;
+    {   // weight-gradient chunk per wave: about 6,000 waves per launch, never below WG_ROWS (7/8/7 jobs on cons/var/cut rows)
+        const long long row_jobs = 7ll * d->n_cons + 8ll * d->n_vars + 7ll * d->n_cuts;
+        const long long want = (row_jobs + 6143) / 6144;
+        jl.wg.rows_per_wave = (int)std::min<long long>(4096, std::max<long long>(WG_ROWS, (want + WG_ROWS - 1) / WG_ROWS * WG_ROWS));
+    }
 
     // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));

@@ -51,19 +51,20 @@ __device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b, flo
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
 // Grouped launch: one job per (X, D) pair, ONE WAVE per WG_ROWS-row chunk of a job; the four waves of a block take four
-// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 512 rows (128-row chunks
-// balance the 1,024 SIMDs better than 256-row ones; 64-row ones drown in prologue).  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
+// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 4 chunks.  Chunk = 128 rows at
+// setcov-500 x 32 (balances the 1,024 SIMDs better than 256; 64 drowns in prologue), scaled up with the row count so that
+// big row sets (capfac: 650 k rows) do not pay for tens of thousands of slabs.  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
 // straight from global memory, every row read exactly once as whole 256-B lines: lane (m, g) loads the float4 at columns
 // 4m..4m+3 of row 4*step+g of X and of D; component va of the X load and component vb of the D load feed accumulator
 // (va, vb), so two loads feed 16 MFMAs.  No LDS or barriers in the main loop; loads run one 16-row batch ahead of the MFMAs.
 // Per-block partial slab [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
 // ---------------------------------------------------------------------------------------------------------------
-#define WG_ROWS 128
+#define WG_ROWS 128   // smallest chunk; big row sets use a multiple (WgArgs.rows_per_wave) so the launch stays at a few thousand waves
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 24
 #define WG_STEPS 4   // 4-row MFMA steps per batch of loads
 struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float* d2; int n; int blk0; int slab0; };
-struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
+struct WgArgs { int njobs; int nblocks; int rows_per_wave; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS], e[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e) {
     while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
     const WgJob jb = a.job[ji];
     const int lb = blockIdx.x - jb.blk0, wv = threadIdx.x >> 6;
-    const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * WG_ROWS), rend = min(jb.n, rbeg + WG_ROWS);   // may be empty: zeros
+    const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * a.rows_per_wave), rend = min(jb.n, rbeg + a.rows_per_wave);   // may be empty: zeros
     float* mine = wg_red + wv * WG_SLAB;
     if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);
     else if (jb.d2) wg_body<2>(jb, mine, rbeg, rend);

@@ -33,7 +33,7 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (auto& c : cfgs) {
-        WgArgs a; a.njobs = c.njobs; a.partial = partial; int blk = 0;
+        WgArgs a; a.njobs = c.njobs; a.partial = partial; a.rows_per_wave = WG_ROWS; int blk = 0;
         for (int j = 0; j < c.njobs; ++j) {
             a.job[j] = WgJob{x + (size_t)j * NMAX * 64, j == 1 ? sx : nullptr, d + (size_t)j * NMAX * 64, c.extra[j] == 1 ? seg : nullptr,
                              c.extra[j] == 2 ? q : nullptr, c.n[j], blk, blk};
