@@ -234,3 +234,46 @@ def test_dp_step_world1_equals_single_gpu_step(dev):
             opt.apply_flat(m, ts.grads)
         outs.append(m.flat_parameters.detach().cpu().numpy().copy())
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-7)
+
+
+def test_train_step_on_degenerate_batches(dev):
+    """Fused loss head + fused Adam on batches that leave the fused fast paths: no cuts at all (every gradient zero, Adam still
+    decays its moments), no constraints (the reduction does not cover every gradient, so Adam runs as its own launch), no
+    edges.  The step must equal the unfused sequence forward -> mse -> backward -> Adam."""
+    from gcnn_cut_selector_amd.trainer import Adam, TrainState, mse_loss, train_step
+    rng = np.random.default_rng(5)
+    z2 = np.zeros((2, 0), np.int32)
+    ei = lambda n_left, n_var, n: np.stack([np.sort(rng.integers(0, n_left, n)), rng.integers(0, n_var, n)]).astype(np.int32)
+    f32 = np.float32
+    cases = {
+        "no cuts": (rng.standard_normal((4, 4)).astype(f32), ei(4, 3, 6), rng.standard_normal((6, 1)).astype(f32),
+                    rng.standard_normal((3, 14)).astype(f32), np.zeros((0, 6), f32), z2, np.zeros((0, 1), f32), 4, 3, 0),
+        "no constraints": (np.zeros((0, 4), f32), z2, np.zeros((0, 1), f32), rng.standard_normal((3, 14)).astype(f32),
+                           rng.standard_normal((5, 6)).astype(f32), ei(5, 3, 7), rng.standard_normal((7, 1)).astype(f32), 0, 3, 5),
+        "no edges": (rng.standard_normal((4, 4)).astype(f32), z2, np.zeros((0, 1), f32), rng.standard_normal((3, 14)).astype(f32),
+                     rng.standard_normal((5, 6)).astype(f32), z2, np.zeros((0, 1), f32), 4, 3, 5),
+    }
+    for name, state in cases.items():
+        y = torch.as_tensor(rng.uniform(0, 0.1, state[9]).astype(f32)).to(dev)
+        outs = []
+        for fused in (True, False):
+            m, _ = _model(60, dev)
+            batch = m.prepare(state)
+            opt, ts = Adam(1e-3), TrainState(m)
+            for _ in range(2):   # second step: the moments are non-zero
+                if fused:
+                    loss, _ = train_step(m, batch, y, opt, ts)
+                else:
+                    flat = m.flat_parameters.detach()
+                    ws = m._take_workspace(batch)
+                    scores = m._forward_into(flat, batch, ws)
+                    loss, d = mse_loss(scores, y)
+                    m._backward_into(flat, batch, ws, d, ts.grads)
+                    m._give_workspace(ws)
+                    opt.apply_flat(m, ts.grads)
+            outs.append((float(loss), ts.grads.cpu().numpy().copy(), m.flat_parameters.detach().cpu().numpy().copy()))
+        (l0, g0, w0), (l1, g1, w1) = outs
+        np.testing.assert_allclose(l0, l1, rtol=1e-5, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(g0, g1, rtol=1e-5, atol=1e-8, err_msg=name)
+        np.testing.assert_allclose(w0, w1, rtol=1e-6, atol=1e-8, err_msg=name)
+        assert np.isfinite(w0).all(), name
