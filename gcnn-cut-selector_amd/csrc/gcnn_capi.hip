@@ -9,7 +9,8 @@
 // Dense(64->64) of the reference (model.py:499-500) is hoisted past the scatter-sum
 //   sum_e (H_e W_f + b_f) = (sum_e H_e) W_f + deg_r b_f
 // so the edge pass only gathers rows, applies ReLU and accumulates in registers (atomic-free segmented sum over
-// receiver-sorted CSR); all 64x64 products run on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with weights staged in LDS.
+// receiver-sorted CSR); all 64x64 products run on the fp32 MFMA (v_mfma_f32_16x16x4_f32; weights in LDS for the row
+// programs, operands straight from global memory for the weight gradients).  A training step is 16 launches on one stream.
 // Wavefront = 64 lanes everywhere.  No atomics on floats anywhere: every sum has a fixed order => bitwise
 // reproducible results.
 
@@ -585,7 +586,7 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
-    // the receiver-ordered half (dP_recv) came out of the chain's epilogue; sender-ordered half: dS rows + 16-B masks,
+    // the receiver-ordered half (dP_recv) came out of the row program's epilogue; sender-ordered half: dS rows + 8-B masks,
     // which also yields Q, the per-sender share of d w_edge
     EdgeArgs e = conv_edge_args(p, c, !c.recv_left);
     e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q; e.mask = c.mask; e.xpos = c.recv_left ? c.g->v2l : c.g->l2v;

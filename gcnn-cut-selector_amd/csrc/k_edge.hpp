@@ -38,7 +38,7 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
 // SAVE also emits what the backward pass needs: per edge one 64-bit word (bit 16k + c = the ReLU bit of channel 4c + k,
 // cut out of four wave-wide compare masks) and per receiver/channel the number N of active edges.  Because dS[r] is
 // constant over a receiver's segment, dP_recv[r] = s1*dS[r]*N[r]: the receiver-ordered half of the backward pass is an
-// element-wise epilogue (of the chain that produces dS), not an edge pass.
+// element-wise epilogue (of the row program that produces dS), not an edge pass.
 template <int SLOTS, bool SAVE, bool NEG>
 __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
 }
 
 // Backward, receiver-ordered half, element-wise: dP_recv[r] = s1*dS[r]*N[r].  (The model fuses this into the epilogue of
-// the chain that produces dS; this kernel serves the per-op entry point.)
+// the row program that produces dS; this kernel serves the per-op entry point.)
 __global__ __launch_bounds__(256) void k_edge_bwd_recv(const float* __restrict__ d_s, const float* __restrict__ nrows,
                                                        const float* __restrict__ s1p, float* __restrict__ d_p, int n4) {
     const float s1 = *s1p;
