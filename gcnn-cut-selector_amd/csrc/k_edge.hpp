@@ -15,7 +15,7 @@ struct EdgeArgs {
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
     const float* d_s;                              // send pass: dS [R,64], gathered by oth
     const int* xpos;                               // send pass: position of each edge in the receiver-ordered list
-    unsigned long long* mask;                      // [E] ReLU bits in receiver order (bit 16k + c = channel 4c + k): fwd writes, send pass reads
+    unsigned long long* mask;                      // [E] ReLU bits in receiver order (nibble c = channels 4c..4c+3): fwd writes, send pass reads
     float* out;                                    // S (fwd) / dP_send
     float* dw_rows;                                // send pass: Q [n_send,64], per-sender share of d w_edge
     float* cnt_rows;                               // fwd (SAVE): N[r] = number of active edges per channel
@@ -35,8 +35,8 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
 
 // Forward edge pass.  relu(s1*J) = s1*max(J,0) for s1 >= 0 and s1*min(J,0) for s1 < 0, so the scale is applied once per
 // receiver.  J_e = (c_e*w + P_oth[oth_e]) + P_own[r].
-// SAVE also emits what the backward pass needs: per edge one 64-bit word (bit 16k + c = the ReLU bit of channel 4c + k,
-// cut out of four wave-wide compare masks) and per receiver/channel the number N of active edges.  Because dS[r] is
+// SAVE also emits what the backward pass needs: per edge one 64-bit word (nibble c = the ReLU bits of channels 4c..4c+3,
+// gathered from the edge's 16 lanes through a per-wave LDS scratch) and per receiver/channel the number N of active edges.  Because dS[r] is
 // constant over a receiver's segment, dP_recv[r] = s1*dS[r]*N[r]: the receiver-ordered half of the backward pass is an
 // element-wise epilogue (of the row program that produces dS), not an edge pass.
 template <int SLOTS, bool SAVE, bool NEG>
@@ -46,10 +46,11 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
     const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
     const float4 w = *(const float4*)(a.w_edge + ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    // storing lane t = gl (< 4*SLOTS) of a receiver handles the edge of step-iteration u = t / SLOTS, slot = t % SLOTS,
-    // whose bits sit at [16f, 16f+16) of the wave masks, f = the receiver's first 16-lane group + slot
-    const int st_u = (gl / SLOTS) & 3;
-    const unsigned st_sh = 16u * ((gbase >> 4) + gl % SLOTS);
+    // per-wave LDS scratch for the ReLU nibbles of one step: [u][lane] bytes; storing lane t = gl (< 4*SLOTS) of a receiver
+    // handles the edge of step-iteration u = t / SLOTS, slot = t % SLOTS, i.e. the 16 bytes at [u][gbase + 16*slot ..]
+    __shared__ __attribute__((aligned(16))) unsigned char nib_all[4][4 * 64];
+    unsigned char* nib_lds = nib_all[wv];
+    const int st_off = ((gl / SLOTS) & 3) * 64 + gbase + 16 * (gl % SLOTS);
 
     const int nwork = (a.n_recv + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
@@ -65,7 +66,7 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                 if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
                 const int cnt = min(G, end - base);
                 for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4]; unsigned long long bal[4][4];
+                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int i = i0 + u * SLOTS + slot;
@@ -87,26 +88,31 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
                             acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
                         }
                         if (SAVE) {
-                            // One compare per channel gives the active bits of all 64 lanes (= 4 edges x 16 lanes) as a wave
-                            // mask; the edge served by 16-lane group f owns bits [16f, 16f+16) of each.
-                            const bool a0 = NEG ? h0 < 0.f : h0 > 0.f, a1 = NEG ? h1 < 0.f : h1 > 0.f;
-                            const bool a2 = NEG ? h2 < 0.f : h2 > 0.f, a3 = NEG ? h3 < 0.f : h3 > 0.f;
-                            n0 += a0; n1 += a1; n2 += a2; n3 += a3;
-                            bal[u][0] = __ballot(a0); bal[u][1] = __ballot(a1); bal[u][2] = __ballot(a2); bal[u][3] = __ballot(a3);
+                            // this lane's four ReLU bits as a nibble; h >= +0 after the ReLU, so "h > 0" can be read off the
+                            // bit pattern: (bits + 0x7fffffff) >> 31  (+0 -> 0, anything positive -> 1)
+                            unsigned b0, b1, b2, b3;
+                            if (NEG) { b0 = h0 < 0.f; b1 = h1 < 0.f; b2 = h2 < 0.f; b3 = h3 < 0.f; }
+                            else {
+                                b0 = (__float_as_uint(h0) + 0x7fffffffu) >> 31; b1 = (__float_as_uint(h1) + 0x7fffffffu) >> 31;
+                                b2 = (__float_as_uint(h2) + 0x7fffffffu) >> 31; b3 = (__float_as_uint(h3) + 0x7fffffffu) >> 31;
+                            }
+                            n0 += b0; n1 += b1; n2 += b2; n3 += b3;
+                            nib_lds[u * 64 + lane] = (unsigned char)(b0 | (b1 << 1) | (b2 << 2) | (b3 << 3));
                         }
                     }
                     if (SAVE) {
-                        // The step's 4*SLOTS edges of this receiver are consecutive in the list: lane t of the receiver's
-                        // lanes assembles the word of edge t = u*SLOTS + slot (bit 16k + c <=> channel 4c + k active)
-                        // and ONE store instruction writes them all.
-                        unsigned f[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const unsigned long long b = st_u == 0 ? bal[0][k] : (st_u == 1 ? bal[1][k] : (st_u == 2 ? bal[2][k] : bal[3][k]));
-                            f[k] = (unsigned)(b >> st_sh) & 0xffffu;
-                        }
+                        // The nibbles of one edge (16 lanes) are 16 consecutive bytes in LDS: storing lane t = gl (< 4*SLOTS) of a
+                        // receiver reads those of edge t = u*SLOTS + slot, squeezes them into the edge's 64-bit word (nibble c =
+                        // channels 4c..4c+3) and ONE store instruction writes the step's consecutive words.  No cross-lane
+                        // VALU traffic: LDS operations of a wave execute in order, so the reads see the writes above.
+                        const uint4 q = *(const uint4*)(nib_lds + st_off);
+                        unsigned x0 = q.x, x1 = q.y, x2 = q.z, x3 = q.w;
+                        x0 = (x0 | (x0 >> 4)) & 0x00ff00ffu; x0 = (x0 | (x0 >> 8)) & 0xffffu;
+                        x1 = (x1 | (x1 >> 4)) & 0x00ff00ffu; x1 = (x1 | (x1 >> 8)) & 0xffffu;
+                        x2 = (x2 | (x2 >> 4)) & 0x00ff00ffu; x2 = (x2 | (x2 >> 8)) & 0xffffu;
+                        x3 = (x3 | (x3 >> 4)) & 0x00ff00ffu; x3 = (x3 | (x3 >> 8)) & 0xffffu;
                         if (gl < 4 * SLOTS && i0 + gl < cnt)
-                            a.mask[base + i0 + gl] = (unsigned long long)(f[0] | (f[1] << 16)) | ((unsigned long long)(f[2] | (f[3] << 16)) << 32);
+                            a.mask[base + i0 + gl] = (unsigned long long)(x0 | (x1 << 16)) | ((unsigned long long)(x2 | (x3 << 16)) << 32);
                     }
                 }
             }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
     const float s1 = *a.s1, esh = *a.e_shift, esc = *a.e_scale;
-    const unsigned bit_a = 1u << cl, bit_b = 1u << (16 + cl);   // mask word: bit 16k + c <=> channel 4c + k (see k_edge_fwd)
+    const unsigned nib_sh = 4u * (cl & 7);   // mask word: nibble c <=> channels 4c..4c+3 (see k_edge_fwd); c < 8 in the low half
     const int nwork = (a.n_recv + RPW - 1) / RPW;
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
         const int u = item * RPW + lane / G;
@@ -180,8 +186,9 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         // rows of inactive slots are zero, so their mask bits do not matter
-                        const float t0 = (wlo[v] & bit_a) ? d[v].x : 0.f, t1 = (wlo[v] & bit_b) ? d[v].y : 0.f;
-                        const float t2 = (whi[v] & bit_a) ? d[v].z : 0.f, t3 = (whi[v] & bit_b) ? d[v].w : 0.f;
+                        const unsigned mb = (cl < 8 ? wlo[v] : whi[v]) >> nib_sh;
+                        const float t0 = (mb & 1u) ? d[v].x : 0.f, t1 = (mb & 2u) ? d[v].y : 0.f;
+                        const float t2 = (mb & 4u) ? d[v].z : 0.f, t3 = (mb & 8u) ? d[v].w : 0.f;
                         acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
                         dw.x = fmaf(ci[v], t0, dw.x); dw.y = fmaf(ci[v], t1, dw.y); dw.z = fmaf(ci[v], t2, dw.z); dw.w = fmaf(ci[v], t3, dw.w);
                     }

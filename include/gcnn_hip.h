@@ -110,8 +110,8 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * (PL[l_e] + c_e*w_edge + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
  *           p_recv = projected table of the receiving side [n_recv,64] (constraint/cut side when from_v=True,
  *           model.py:553-556), p_oth = the other side's table, gathered by oth[e].
- *           Optional outputs for the backward pass (both or none): mask_out [E] uint64 in receiver order, bit 16k+c of
- *           word e (k < 4, c < 16) is [s1*J_e > 0] for channel 4c+k; n_rows [n_recv,64] = number of active edges per
+ *           Optional outputs for the backward pass (both or none): mask_out [E] uint64 in receiver order, nibble c of
+ *           word e holds the bits [s1*J_e > 0] of channels 4c..4c+3; n_rows [n_recv,64] = number of active edges per
  *           receiver and channel.
  * bwd_recv: element-wise, because d_s[r] is constant over a segment: d_p_recv = s1*d_s*n_rows.
  * bwd_send: segments grouped by the SENDING node; with t_e = mask[xpos[e]] * d_s[oth[e]]:
