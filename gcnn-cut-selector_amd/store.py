@@ -164,10 +164,10 @@ class SampleStore:
 
     def batch(self, ids) -> StoreBatch:
         """Mini-batch of the samples `ids` (any order, repeats allowed), equal array for array to
-        `GCNN.prepare(utils.collate([samples[i] for i in ids]))`."""
+        `GCNN.prepare(utils.collate([samples[i] for i in ids]))`.  No ids: an empty batch."""
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
-        if len(ids) == 0:
-            raise ValueError("empty batch")
+        if len(ids) == 0:   # a data-parallel rank may draw no sample of a short last batch: an empty batch still takes part
+            return self._empty_batch()
         if ids.min() < 0 or ids.max() >= len(self):
             raise IndexError("sample id out of range")
         dev, b = self.device, len(ids)
@@ -223,9 +223,25 @@ class SampleStore:
         return StoreBatch(batch, sizes[_K_CONS].astype(np.int32), sizes[_K_VAR].astype(np.int32),
                           sizes[_K_CUT].astype(np.int32), f32("improvements", n_k))
 
-    def batches(self, ids, batch_size):
+    def _empty_batch(self) -> StoreBatch:
+        dev = self.device
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+        graph = lambda: BipartiteGraph.from_plan(0, 0, i32(1), i32(0), f32(0), i32(1), i32(0), f32(0), i32(0), i32(0))
+        z = np.zeros(0, np.int32)
+        return StoreBatch(Batch(f32(0, 4), f32(0, 14), f32(0, 6), graph(), graph()), z, z, z, f32(0))
+
+    def batches(self, ids, batch_size, rank=0, world_size=1):
         """Counterpart of `Dataset.from_tensor_slices(files).batch(batch_size).map(load_batch)`
-        (model_trainer.py:115-125,150-153): consecutive groups of `batch_size` ids, the last one possibly short."""
+        (model_trainer.py:115-125,150-153): consecutive groups of `batch_size` ids, the last one possibly short.
+        Data parallel (`world_size` > 1; every rank holds the store and passes the SAME ids): each global batch is split
+        by edge count (`parallel.shard_samples`) and this rank's share is collated -- possibly an empty batch, which still
+        has to go through `train_step` so that the all-reduce matches up."""
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
         for i in range(0, len(ids), batch_size):
-            yield self.batch(ids[i:i + batch_size])
+            group = ids[i:i + batch_size]
+            if world_size > 1:
+                from .parallel import shard_samples
+                edges = self.sizes[_K_E1, group] + self.sizes[_K_E2, group]
+                group = group[shard_samples(edges, world_size)[rank]]
+            yield self.batch(group)

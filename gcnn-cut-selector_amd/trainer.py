@@ -191,9 +191,10 @@ def ranking_fraction(pred: np.ndarray, true: np.ndarray) -> float:
 
 
 def ranking_metric(pred: torch.Tensor, true: torch.Tensor, n_cuts, fractions_dev: torch.Tensor, acc: torch.Tensor,
-                   loss: torch.Tensor | None = None, loss_acc: torch.Tensor | None = None):
+                   loss: torch.Tensor | None = None, loss_acc: torch.Tensor | None = None, loss_weight: float | None = None):
     """Device-side ranking-prefix accuracy (gcnn_ranking_metric): acc[f] += #samples with frac >= fractions[f]; optionally
-    loss_acc += loss * total_cuts (the cut-weighted loss of model_trainer.py:304).  Returns per-sample fractions (device)."""
+    loss_acc += loss * loss_weight (default: total_cuts, the cut-weighted loss of model_trainer.py:304).  Returns per-sample
+    fractions (device)."""
     n_cuts = np.asarray(n_cuts, dtype=np.int64).reshape(-1)
     offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(n_cuts)]).astype(np.int32)).to(pred.device, non_blocking=True)
     frac = torch.empty(len(n_cuts), dtype=torch.float32, device=pred.device)
@@ -201,15 +202,21 @@ def ranking_metric(pred: torch.Tensor, true: torch.Tensor, n_cuts, fractions_dev
         _lib.check(_lib.lib().gcnn_ranking_metric(_ptr(pred), _ptr(true), _ptr(offsets), len(n_cuts),
                                                   int(n_cuts.max()) if len(n_cuts) else 0, _ptr(fractions_dev),
                                                   fractions_dev.numel(), _ptr(acc), _ptr(frac), _ptr(loss),
-                                                  float(n_cuts.sum()), _ptr(loss_acc), _stream(pred.device)),
+                                                  float(n_cuts.sum()) if loss_weight is None else float(loss_weight), _ptr(loss_acc),
+                                                  _stream(pred.device)),
                    "gcnn_ranking_metric")
     return frac
 
 
-def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | None = None):
+def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | None = None, process_group=None):
     """Counterpart of model_trainer.process (model_trainer.py:239-316).  `dataloader` yields the 11-tuples of
-    `utils.load_batch` (per-sample count vectors + improvements).  Returns (cut-weighted mean loss, accuracy per fraction).
-    Loss and ranking accuracy accumulate ON THE DEVICE; the host reads them once at the end (no per-batch sync)."""
+    `utils.load_batch` (per-sample count vectors + improvements) or `SampleStore` batches.  Returns (cut-weighted mean loss,
+    accuracy per fraction).  Loss and ranking accuracy accumulate ON THE DEVICE; the host reads them once at the end (no
+    per-batch sync).
+
+    Data parallel (`process_group` given): every rank iterates over ITS shard of each global batch (e.g.
+    `store.batches(ids, batch_size, rank, world_size)`, the same number of batches on every rank, empty shards included);
+    gradients are all-reduced per step (`train_step`) and the returned loss / accuracies are those of the GLOBAL data."""
     dev = model.device
     fractions = np.asarray(fractions, dtype=np.float32)
     frac_dev = torch.from_numpy(fractions).to(dev)
@@ -228,28 +235,39 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | No
                 prepared = model.prepare((c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)),
                                           int(n_cuts.sum())))
                 y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(dev, non_blocking=True)
+            total = int(n_cuts.sum())
             if optimizer is not None:
-                loss, predictions = train_step(model, prepared, y, optimizer, state)
+                # data parallel: `loss` is the local SUM of squared errors (train_step), else the mean over this batch
+                loss, predictions = train_step(model, prepared, y, optimizer, state, process_group=process_group)
+                weight = 1.0 if process_group is not None else float(total)
             else:
                 with torch.no_grad():
                     predictions = model(prepared, False)
                 loss, _ = mse_loss(predictions, y, want_grad=False)
-            total = int(n_cuts.sum())
-            if len(n_cuts) and n_cuts.max() <= 4096:
-                ranking_metric(predictions.detach().as_subclass(torch.Tensor), y, n_cuts, frac_dev, acc_dev, loss, loss_dev)
+                weight = float(total)
+            if len(n_cuts) == 0:
+                pass
+            elif n_cuts.max() <= 4096:
+                ranking_metric(predictions.detach().as_subclass(torch.Tensor), y, n_cuts, frac_dev, acc_dev, loss, loss_dev, weight)
             else:
                 pred, true = predictions.detach().cpu().numpy(), y.cpu().numpy()
                 start = 0
                 for nk in n_cuts:
                     host_acc += ranking_fraction(pred[start:start + nk], true[start:start + nk]) >= fractions
                     start += nk
-                host_loss += float(loss) * total
+                host_loss += float(loss) * weight
             n_samples += len(n_cuts)
             cut_count += total
         except torch.OutOfMemoryError:  # the reference skips batches that exhaust memory (model_trainer.py:308-311)
             print("WARNING: batch skipped.")
-    mean_loss = (float(loss_dev.item()) + host_loss) / max(cut_count, 1)
-    mean_acc = (acc_dev.cpu().numpy().astype(np.float64) + host_acc) / max(n_samples, 1)
+    totals = torch.cat([loss_dev.double() + host_loss, acc_dev.double() + torch.from_numpy(host_acc).to(dev),
+                        torch.tensor([float(n_samples), float(cut_count)], dtype=torch.float64, device=dev)])
+    if process_group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM, group=process_group)
+    totals = totals.cpu().numpy()
+    mean_loss = float(totals[0]) / max(totals[-1], 1.0)
+    mean_acc = totals[1:-2] / max(totals[-2], 1.0)
     return mean_loss, mean_acc
 
 

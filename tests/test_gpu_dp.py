@@ -46,13 +46,23 @@ def _worker(rank, world, port, out_path):
     ts = TrainState(m)
     train_step(m, sb.batch, sb.improvements, None, ts, process_group=dist.group.WORLD)
     torch.cuda.synchronize()
+    # the reference-style epoch loop, data parallel: two training batches (the second one short), then an evaluation pass
+    # with single-sample batches, where one of the two ranks always holds an empty shard
+    from gcnn_cut_selector_amd.trainer import Adam, process
+    fractions = np.array([0.25, 0.5, 0.75, 1.0])
+    opt = Adam(learning_rate=lambda: 1e-3)
+    ids = np.arange(N_SAMPLES)
+    train = process(m, store.batches(ids, 4, rank, world), fractions, opt, process_group=dist.group.WORLD)
+    valid = process(m, store.batches(ids[:3], 1, rank, world), fractions, process_group=dist.group.WORLD)
+    torch.cuda.synchronize()
     if rank == 0:
-        np.savez(out_path, buf=ts.buf.cpu().numpy(), mine=np.asarray(mine))
+        np.savez(out_path, buf=ts.buf.cpu().numpy(), mine=np.asarray(mine), train_loss=train[0], train_acc=train[1],
+                 valid_loss=valid[0], valid_acc=valid[1], weights=m.flat_parameters.detach().cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_equals_single_process_gradient(tmp_path):
+def test_two_rank_gradient_and_epoch_loop_equal_single_process(tmp_path):
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     import torch.multiprocessing as mp
     from gcnn_cut_selector_amd.model import GCNN
@@ -78,3 +88,17 @@ def test_two_rank_gradient_equals_single_process_gradient(tmp_path):
     assert count == sb.batch.dims.n_cuts                      # the reduced count slot = cuts of the GLOBAL batch
     assert 0 < len(got["mine"]) < N_SAMPLES                    # rank 0 really held only a shard
     np.testing.assert_allclose(got["buf"][:n] / count, want, rtol=2e-4, atol=2e-6 * np.abs(want).max())
+    # the same epoch loop in one process on the global batches
+    from gcnn_cut_selector_amd.trainer import Adam, process
+    fractions = np.array([0.25, 0.5, 0.75, 1.0])
+    store = SampleStore.from_samples(samples, dev)
+    opt = Adam(learning_rate=lambda: 1e-3)
+    ids = np.arange(N_SAMPLES)
+    train = process(m, store.batches(ids, 4), fractions, opt)
+    valid = process(m, store.batches(ids[:3], 1), fractions)
+    np.testing.assert_allclose(got["train_loss"], train[0], rtol=1e-4)
+    np.testing.assert_allclose(got["valid_loss"], valid[0], rtol=1e-4)
+    np.testing.assert_array_equal(got["train_acc"], train[1])
+    np.testing.assert_array_equal(got["valid_acc"], valid[1])
+    w = m.flat_parameters.detach().cpu().numpy()
+    np.testing.assert_allclose(got["weights"], w, rtol=1e-3, atol=1e-5)       # two Adam steps on (almost) equal gradients
