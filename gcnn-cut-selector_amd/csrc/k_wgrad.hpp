@@ -140,8 +140,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e) {
         embed1_wgrad_block(e, blockIdx.x - a.nblocks, wg_red);
         return;
     }
-    int ji = 0;
-    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
+    int ji = 0;   // last job whose first block is <= this block: binary search (a linear scan is one dependent scalar load per job)
+    for (int hi = a.njobs; hi - ji > 1;) {
+        const int mid = (ji + hi) >> 1;
+        if ((int)blockIdx.x >= a.job[mid].blk0) ji = mid; else hi = mid;
+    }
     const WgJob jb = a.job[ji];
     const int lb = blockIdx.x - jb.blk0, wv = threadIdx.x >> 6;
     const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * a.rows_per_wave), rend = min(jb.n, rbeg + a.rows_per_wave);   // may be empty: zeros
@@ -171,8 +174,11 @@ struct RdArgs { int njobs; float* cdst; float cval; RdAdam adam; RdJob job[RD_MA
 __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
     __shared__ float red[4][EMB];
     if (a.cdst && blockIdx.x == 0 && threadIdx.x == 0) *a.cdst = a.cval;
-    int ji = 0;
-    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].blk0) ++ji;
+    int ji = 0;   // binary search over up to 96 jobs
+    for (int hi = a.njobs; hi - ji > 1;) {
+        const int mid = (ji + hi) >> 1;
+        if ((int)blockIdx.x >= a.job[mid].blk0) ji = mid; else hi = mid;
+    }
     const RdJob jb = a.job[ji];
     const int chunk = blockIdx.x - jb.blk0;
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
