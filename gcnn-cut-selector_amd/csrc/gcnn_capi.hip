@@ -28,16 +28,27 @@
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// hipFuncSetAttribute acts on the current device's copy of a kernel: remember it per device, not per process
+#define GCNN_MAX_DEVICES 64
+struct PerDeviceOnce {
+    bool done[GCNN_MAX_DEVICES] = {};
+    bool first() {   // true the first time on the current device (always true for a device id outside the table)
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= GCNN_MAX_DEVICES) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
 static const int LIN_SMEM = (2 * 64 * LDW + 4 * 32 * LDW) * (int)sizeof(float);  // 69,632 B
 static const int MAX_GRID = 2048;
 
 static int launch_linear(bool transb, const LinArgs& a, hipStream_t st) {
     if (a.n <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {  // 68 KB of dynamic LDS per block (gfx950 has 160 KB per CU)
+    static PerDeviceOnce attr;
+    if (attr.first()) {  // 68 KB of dynamic LDS per block (gfx950 has 160 KB per CU)
         HIPCHK(hipFuncSetAttribute((const void*)k_linear<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM));
         HIPCHK(hipFuncSetAttribute((const void*)k_linear<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_SMEM));
-        attr_set = true;
     }
     const int grid = std::min(cdiv(a.n, 128), MAX_GRID);
     if (transb) hipLaunchKernelGGL(k_linear<true>, dim3(grid), dim3(256), LIN_SMEM, st, a);
@@ -376,11 +387,10 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
 }
 #define ROWS_LAUNCH(KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ARGS)                                                     \
     do {                                                                                                                \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
+        static PerDeviceOnce attr;                                                                                      \
+        if (attr.first()) {                                                                                             \
             HIPCHK(hipFuncSetAttribute((const void*)KERNEL8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
             HIPCHK(hipFuncSetAttribute((const void*)KERNEL4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
-            attr_set = true;                                                                                            \
         }                                                                                                               \
         if ((NWAVES) == 8) hipLaunchKernelGGL(KERNEL8, dim3(GRID), dim3(512), SMEM, ST, ARGS);                          \
         else hipLaunchKernelGGL(KERNEL4, dim3(GRID), dim3(256), SMEM, ST, ARGS);                                        \
@@ -718,9 +728,9 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
     if (jl.wg.nblocks + ea.nblocks > 0) {
-        static bool attr_set = false;
+        static PerDeviceOnce attr;
         const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+        if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64 * WG_WAVES), smem, st, jl.wg, ea);
         LAUNCHCHK();
     }
@@ -795,7 +805,7 @@ extern "C" int gcnn_adam_step(float* params, const float* grads, float* m, float
 extern "C" int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
                                   const float* grad_scale, int32_t scale_is_divisor, void* stream) {
     if (n < 0 || !opt_state || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
-    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, opt_state);
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, opt_state, grad_scale, scale_is_divisor);
     LAUNCHCHK();
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_adam_dev, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,

@@ -59,6 +59,9 @@ __global__ __launch_bounds__(256) void k_score_bwd(const float* __restrict__ d_s
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int n, float lr_t, float b1, float b2, float eps,
                                               const float* __restrict__ gscale, int recip) {
+    // recip: *gscale is the all-reduced cut count of a data-parallel step.  A global batch without a single cut has no
+    // loss (model_trainer.py:271 would average over nothing): that is "no step" -- weights and moments stay as they are.
+    if (gscale && recip && !(*gscale > 0.f)) return;
     const float gs = gscale ? (recip ? 1.f / *gscale : *gscale) : 1.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float gi = g[i] * gs;
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // The same update with every hyper-parameter and the step counter resident on the device, so that a captured hipGraph
 // can be replayed step after step: opt = {lr, beta1, beta2, eps, t (step count), lr_t}.  k_adam_tick advances t and
 // computes lr_t = lr*sqrt(1-b2^t)/(1-b1^t) in double; k_adam_dev applies it.
-__global__ void k_adam_tick(float* __restrict__ opt) {
+__global__ void k_adam_tick(float* __restrict__ opt, const float* __restrict__ gscale, int recip) {
+    if (gscale && recip && !(*gscale > 0.f)) return;   // a global batch without cuts is no step (see k_adam)
     const double t = (double)opt[4] + 1.0;
     opt[4] = (float)t;
     opt[5] = (float)((double)opt[0] * sqrt(1.0 - pow((double)opt[2], t)) / (1.0 - pow((double)opt[1], t)));
@@ -79,6 +83,9 @@ __global__ void k_adam_tick(float* __restrict__ opt) {
 __global__ __launch_bounds__(256) void k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int n, const float* __restrict__ opt,
                                                   const float* __restrict__ gscale, int recip) {
+    // recip: *gscale is the all-reduced cut count of a data-parallel step.  A global batch without a single cut has no
+    // loss (model_trainer.py:271 would average over nothing): that is "no step" -- weights and moments stay as they are.
+    if (gscale && recip && !(*gscale > 0.f)) return;
     const float gs = gscale ? (recip ? 1.f / *gscale : *gscale) : 1.f;
     const float b1 = opt[1], b2 = opt[2], eps = opt[3], lr_t = opt[5];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {

@@ -19,7 +19,7 @@ import pickle
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, _safe_pickle
 from .graph import BipartiteGraph, _ptr, _stream
 
 EMB = 64
@@ -225,11 +225,11 @@ class GCNN:
                 pickle.dump(a, file)
 
     def restore_state(self, path: str):
-        """model.py:58-67."""
+        """model.py:58-67.  The records are read with an unpickler that admits NumPy arrays only (`_safe_pickle`)."""
         arrays = []
         with open(path, "rb") as file:
             for _ in VARIABLE_SPEC:
-                arrays.append(pickle.load(file))
+                arrays.append(_safe_pickle.load(file))
         self.set_weights(arrays)
 
     # ---- inputs ------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 """Training-step counterpart of the reference's `model_trainer.py` for the HIP GCNN.
 
 Mirrors (file:line in /root/reference):
-  process(model, dataloader, fractions, loss_fn, optimizer)  model_trainer.py:239-316  -> process()
+  process(model, dataloader, fractions, loss_fn, optimizer)  model_trainer.py:239-316  -> process() (same positional order)
   pretrain(model, dataloader)                                 model_trainer.py:194-236  -> pretrain()
   MeanSquaredError / Adam(learning_rate=lambda: lr)           model_trainer.py:131-132  -> mse_loss() / Adam
   ranking-prefix accuracy                                     model_trainer.py:280-302  -> ranking_fraction()
@@ -208,15 +208,35 @@ def ranking_metric(pred: torch.Tensor, true: torch.Tensor, n_cuts, fractions_dev
     return frac
 
 
-def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | None = None, process_group=None):
-    """Counterpart of model_trainer.process (model_trainer.py:239-316).  `dataloader` yields the 11-tuples of
-    `utils.load_batch` (per-sample count vectors + improvements) or `SampleStore` batches.  Returns (cut-weighted mean loss,
-    accuracy per fraction).  Loss and ranking accuracy accumulate ON THE DEVICE; the host reads them once at the end (no
-    per-batch sync).
+def _unpack_batch(model: GCNN, batch):
+    """`utils.load_batch` 11-tuple or `SampleStore` batch -> (prepared Batch, per-sample n_cuts, device targets)."""
+    if isinstance(batch, StoreBatch):     # collated on the device by a SampleStore: nothing left to move
+        return batch.batch, np.asarray(batch.n_cuts).reshape(-1), batch.improvements
+    (c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts, improvements) = batch
+    n_cuts = np.asarray(n_cuts).reshape(-1)
+    prepared = model.prepare((c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)), int(n_cuts.sum())))
+    y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(model.device, non_blocking=True)
+    return prepared, n_cuts, y
 
-    Data parallel (`process_group` given): every rank iterates over ITS shard of each global batch (e.g.
+
+def process(model: GCNN, dataloader, fractions: np.ndarray, loss_fn=None, optimizer: Adam | None = None, *,
+            process_group=None):
+    """Counterpart of model_trainer.process (model_trainer.py:239-316), same positional order:
+    `process(model, dataloader, fractions, loss_fn, optimizer=None)`.  `loss_fn` keeps the reference's slot so its call sites
+    (model_trainer.py:156,161,182) bind unchanged; the loss is always the reference's `MeanSquaredError`
+    (model_trainer.py:132) evaluated by the fused loss head, so a callable (or None) is accepted and not called.
+    `dataloader` yields the 11-tuples of `utils.load_batch` (per-sample count vectors + improvements) or `SampleStore`
+    batches.  Returns (cut-weighted mean loss, accuracy per fraction).  Loss and ranking accuracy accumulate ON THE DEVICE;
+    the host reads them once at the end (no per-batch sync).
+
+    Data parallel (`process_group` given, keyword only): every rank iterates over ITS shard of each global batch (e.g.
     `store.batches(ids, batch_size, rank, world_size)`, the same number of batches on every rank, empty shards included);
     gradients are all-reduced per step (`train_step`) and the returned loss / accuracies are those of the GLOBAL data."""
+    if isinstance(loss_fn, Adam):
+        raise TypeError("process(model, dataloader, fractions, loss_fn, optimizer): the fourth positional argument is the "
+                        "reference's loss_fn slot; pass the optimizer fifth (or optimizer=...)")
+    if loss_fn is not None and not callable(loss_fn):
+        raise TypeError("loss_fn must be None or a callable (it is accepted for call compatibility and not called)")
     dev = model.device
     fractions = np.asarray(fractions, dtype=np.float32)
     frac_dev = torch.from_numpy(fractions).to(dev)
@@ -227,14 +247,7 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | No
     state = TrainState(model) if optimizer is not None else None
     for batch in dataloader:
         try:
-            if isinstance(batch, StoreBatch):     # collated on the device by a SampleStore: nothing left to move
-                prepared, n_cuts, y = batch.batch, np.asarray(batch.n_cuts).reshape(-1), batch.improvements
-            else:
-                (c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts, improvements) = batch
-                n_cuts = np.asarray(n_cuts).reshape(-1)
-                prepared = model.prepare((c, cei, cef, v, k, kei, kef, int(np.sum(n_cons)), int(np.sum(n_vars)),
-                                          int(n_cuts.sum())))
-                y = torch.as_tensor(np.asarray(improvements), dtype=torch.float32).to(dev, non_blocking=True)
+            prepared, n_cuts, y = _unpack_batch(model, batch)
             total = int(n_cuts.sum())
             if optimizer is not None:
                 # data parallel: `loss` is the local SUM of squared errors (train_step), else the mean over this batch
@@ -259,6 +272,11 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, optimizer: Adam | No
             n_samples += len(n_cuts)
             cut_count += total
         except torch.OutOfMemoryError:  # the reference skips batches that exhaust memory (model_trainer.py:308-311)
+            if process_group is not None:
+                # Data parallel: the peers are in (or heading for) this step's all-reduce; a rank that skipped on its own
+                # would pair that collective with its next batch.  Agreeing on a skip costs a blocking collective per batch,
+                # so the error propagates instead (with the store resident in HBM a batch that does not fit is a sizing bug).
+                raise
             print("WARNING: batch skipped.")
     totals = torch.cat([loss_dev.double() + host_loss, acc_dev.double() + torch.from_numpy(host_acc).to(dev),
                         torch.tensor([float(n_samples), float(cut_count)], dtype=torch.float64, device=dev)])

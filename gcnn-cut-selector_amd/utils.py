@@ -14,6 +14,8 @@ import pickle
 
 import numpy as np
 
+from . import _safe_pickle
+
 
 def save_sample(path: str, state, improvements):
     """Write one (state, improvements) pair in the reference's on-disk format (data_collector.py:135-140)."""
@@ -22,8 +24,9 @@ def save_sample(path: str, state, improvements):
 
 
 def load_sample(path: str):
+    """One sample file -> [state, improvements]; unpickled with NumPy arrays / builtin containers admitted only."""
     with gzip.open(path, "rb") as file:
-        sample = pickle.load(file)
+        sample = _safe_pickle.load(file)
     return sample["data"]
 
 
@@ -35,7 +38,8 @@ def collate(samples):
     n_cons = [c.shape[0] for c in cons]
     n_vars = [v.shape[0] for v in var]
     n_cuts = [k.shape[0] for k in cut]
-    # cons_shift = [[0, n_cons_1, n_cons_1 + n_cons_2, ...], [0, n_var_1, ...]] (utils.py:401-407)
+    # index offset of every sample inside the disjoint union: exclusive prefix sums of the row / column counts, one
+    # column per sample (the formula of utils.py:401-407 is the batching contract)
     cons_shift = np.cumsum([[0] + n_cons[:-1], [0] + n_vars[:-1]], axis=1)
     cut_shift = np.cumsum([[0] + n_cuts[:-1], [0] + n_vars[:-1]], axis=1)
     cei = np.concatenate([s[0][1]["indices"] + cons_shift[:, j:j + 1] for j, s in enumerate(samples)], axis=1)

@@ -188,13 +188,16 @@ int gcnn_prenorm_stats(const gcnn_dims* dims, const float* params, const float* 
 /* ---- Keras-form Adam over the flat buffer: model_trainer.py:131,273 ------------------------------------------
  * theta -= lr_t * m / (sqrt(v) + eps), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller (host double).
  * grad_scale (optional device scalar, may be NULL) multiplies every gradient first -- or divides it when
- * scale_is_divisor != 0 (data parallel: the all-reduced global cut count). */
+ * scale_is_divisor != 0 (data parallel: the all-reduced global cut count).  A divisor that is not > 0 (a global batch
+ * without a single cut: model_trainer.py:271 would average over nothing) makes the call a no-op: parameters and moments
+ * keep their values instead of turning into NaN. */
 int gcnn_adam_step(float* params, const float* grads, float* m, float* v, int32_t n, float lr_t, float beta1,
                    float beta2, float eps, const float* grad_scale, int32_t scale_is_divisor, void* stream);
 
 /* The same update with hyper-parameters and step counter on the device, so that a captured hipGraph of a whole training
  * step can be replayed: opt_state = {lr, beta1, beta2, eps, t, lr_t} (6 floats, device).  Each call advances t by one and
- * recomputes lr_t; the caller changes lr (the plateau schedule of model_trainer.py:177-179) by writing opt_state[0]. */
+ * recomputes lr_t; the caller changes lr (the plateau schedule of model_trainer.py:177-179) by writing opt_state[0].
+ * With a divisor that is not > 0 neither t nor any parameter changes (see gcnn_adam_step). */
 int gcnn_adam_step_dev(float* params, const float* grads, float* m, float* v, int32_t n, float* opt_state,
                        const float* grad_scale, int32_t scale_is_divisor, void* stream);
 

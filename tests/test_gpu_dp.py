@@ -52,7 +52,7 @@ def _worker(rank, world, port, out_path):
     fractions = np.array([0.25, 0.5, 0.75, 1.0])
     opt = Adam(learning_rate=lambda: 1e-3)
     ids = np.arange(N_SAMPLES)
-    train = process(m, store.batches(ids, 4, rank, world), fractions, opt, process_group=dist.group.WORLD)
+    train = process(m, store.batches(ids, 4, rank, world), fractions, None, opt, process_group=dist.group.WORLD)
     valid = process(m, store.batches(ids[:3], 1, rank, world), fractions, process_group=dist.group.WORLD)
     torch.cuda.synchronize()
     if rank == 0:
@@ -94,7 +94,7 @@ def test_two_rank_gradient_and_epoch_loop_equal_single_process(tmp_path):
     store = SampleStore.from_samples(samples, dev)
     opt = Adam(learning_rate=lambda: 1e-3)
     ids = np.arange(N_SAMPLES)
-    train = process(m, store.batches(ids, 4), fractions, opt)
+    train = process(m, store.batches(ids, 4), fractions, None, opt)
     valid = process(m, store.batches(ids[:3], 1), fractions)
     np.testing.assert_allclose(got["train_loss"], train[0], rtol=1e-4)
     np.testing.assert_allclose(got["valid_loss"], valid[0], rtol=1e-4)

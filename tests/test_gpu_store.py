@@ -93,7 +93,7 @@ def test_store_from_files_and_process_match_the_host_loader(dev, tmp_path):
             loader = lambda idx, bs: [utils.load_batch([files[i] for i in idx[j:j + bs]]) for j in range(0, len(idx), bs)]
         n_layers = pretrain(m, loader(np.arange(len(files)), 4))
         opt = Adam(learning_rate=lambda: 1e-3)
-        train = process(m, loader(ids, 6), fractions, opt)
+        train = process(m, loader(ids, 6), fractions, None, opt)
         valid = process(m, loader(np.arange(len(files)), 5), fractions)
         results.append((n_layers, train, valid, m.flat_parameters.detach().cpu().numpy().copy()))
     (n0, t0, v0, w0), (n1, t1, v1, w1) = results

@@ -90,7 +90,7 @@ def test_process_and_pretrain_mirror_reference_flow(dev, tmp_path):
     loss0, acc0 = process(m, loader, fractions)
     opt = Adam(learning_rate=lambda: 1e-3)
     for _ in range(15):
-        train_loss, _ = process(m, loader, fractions, opt)
+        train_loss, _ = process(m, loader, fractions, lambda y_true, y_pred: None, opt)   # the reference's positional order
     loss1, acc1 = process(m, loader, fractions)
     assert np.isfinite(loss0) and loss1 < loss0 and acc1.shape == (4,)
     # validation loss = cut-weighted mean of per-batch MSE (model_trainer.py:304,313), checked against the oracle
@@ -277,3 +277,51 @@ def test_train_step_on_degenerate_batches(dev):
         np.testing.assert_allclose(g0, g1, rtol=1e-5, atol=1e-8, err_msg=name)
         np.testing.assert_allclose(w0, w1, rtol=1e-6, atol=1e-8, err_msg=name)
         assert np.isfinite(w0).all(), name
+
+
+def test_tester_process_matches_reference_semantics(dev, tmp_path):
+    """tester.process vs model_tester.py:173-237 restated with the oracle: cut-weighted MSE and the MEAN ranking fraction."""
+    from gcnn_cut_selector_amd import tester
+    from gcnn_cut_selector_amd.store import SampleStore
+    m, params = _model(70, dev)
+    samples = [synthetic.make_sample("combauc", 300 + i) for i in range(5)] + [synthetic.make_sample("setcov", 300, scale=0.2)]
+    files = []
+    for i, (state, imp) in enumerate(samples):
+        f = str(tmp_path / f"sample_{i}.pkl"); utils.save_sample(f, state, imp); files.append(f)
+    loader = [utils.load_batch(files[i:i + 4]) for i in range(0, len(files), 4)]     # a full and a short batch
+    loss, mean_acc = tester.process(m, loader)
+    tot = cnt = fr = 0.0
+    for b in loader:
+        st = b[:7] + (int(b[7].sum()), int(b[8].sum()), int(b[9].sum()))
+        pred = O.scores(params, st, torch.float32)
+        tot += float(((pred - b[10]) ** 2).sum()); cnt += len(pred)
+        start = 0
+        for nk in b[9]:
+            fr += O.ranking_fraction(pred[start:start + nk], b[10][start:start + nk]); start += nk
+    np.testing.assert_allclose(loss, tot / cnt, rtol=1e-4)
+    np.testing.assert_allclose(mean_acc, fr / len(samples), rtol=1e-6)
+    # the same through a device-resident store
+    store = SampleStore.from_samples(samples, dev)
+    loss2, acc2 = tester.process(m, store.batches(np.arange(len(samples)), 4))
+    np.testing.assert_allclose([loss2, acc2], [loss, mean_acc], rtol=1e-6)
+
+
+def test_adam_with_zero_global_cut_count_is_no_step(dev):
+    """Data parallel: Adam divides by the all-reduced cut count; a global batch without cuts must leave weights, moments and
+    the device-side step counter untouched (not 0 * inf = NaN)."""
+    from gcnn_cut_selector_amd.trainer import Adam
+    m, _ = _model(71, dev)
+    before = m.flat_parameters.detach().clone()
+    g = torch.zeros_like(before)
+    zero = torch.zeros(1, device=dev)
+    opt = Adam(1e-3)
+    opt.apply_flat(m, torch.randn_like(before) * m._trainable_mask)          # a real step first: moments are non-zero
+    w1, m1, v1 = m.flat_parameters.detach().clone(), opt.m.clone(), opt.v.clone()
+    opt.apply_flat(m, g, grad_scale=zero, divide=True)
+    opt.apply_flat_dev(m, g, grad_scale=zero, divide=True)
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_parameters.detach(), w1) and torch.equal(opt.m, m1) and torch.equal(opt.v, v1)
+    assert bool(torch.isfinite(m.flat_parameters.detach()).all())
+    t_dev = float(opt._dev[4])
+    opt.apply_flat_dev(m, g, grad_scale=torch.ones(1, device=dev), divide=True)
+    assert float(opt._dev[4]) == t_dev + 1

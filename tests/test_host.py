@@ -132,3 +132,70 @@ def test_data_parallel_gradient_equals_global_batch_gradient(tmp_path):
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), f"dp_{r}.npy"))
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6 * np.abs(want).max())  # the packed buffer is fp32
+
+
+def test_process_binds_the_reference_positional_order(monkeypatch):
+    """model_trainer.py:156,161,182 call `process(model, data, fractions, loss_fn[, optimizer])` positionally: the fourth slot
+    is the loss function, the fifth the optimizer.  Checked on the CPU with the device calls stubbed out."""
+    from gcnn_cut_selector_amd import trainer
+
+    class FakeModel:
+        device = torch.device("cpu")
+        flat_parameters = torch.zeros(8)
+
+        def prepare(self, inputs):
+            return inputs
+
+        def __call__(self, batch, training):
+            return torch.zeros(3)
+
+    seen = []
+
+    def fake_train_step(model, batch, y, optimizer, state, process_group=None):
+        seen.append(("train", optimizer, process_group))
+        return torch.ones(1), torch.zeros(3)
+
+    monkeypatch.setattr(trainer, "train_step", fake_train_step)
+    monkeypatch.setattr(trainer, "mse_loss", lambda pred, y, scale=None, want_grad=True: (seen.append(("eval", None, None)) or torch.ones(1), None))
+    monkeypatch.setattr(trainer, "ranking_metric", lambda *a, **k: None)
+    z = np.zeros
+    batch = (z((1, 4), np.float32), z((2, 0), np.int32), z((0, 1), np.float32), z((1, 14), np.float32), z((3, 6), np.float32),
+             z((2, 0), np.int32), z((0, 1), np.float32), np.array([1]), np.array([1]), np.array([3]), z(3, np.float32))
+    loss_fn = lambda y_true, y_pred: None       # stands for tf.keras.losses.MeanSquaredError() (model_trainer.py:132)
+    opt = trainer.Adam(learning_rate=lambda: 1e-3)
+    fractions = np.array([0.25, 0.5, 0.75, 1])
+    trainer.process(FakeModel(), [batch], fractions, loss_fn, opt)          # model_trainer.py:156
+    trainer.process(FakeModel(), [batch], fractions, loss_fn)               # model_trainer.py:161,182
+    assert seen == [("train", opt, None), ("eval", None, None)]
+    with pytest.raises(TypeError):                                           # round-1 call order: optimizer in the loss_fn slot
+        trainer.process(FakeModel(), [batch], fractions, opt)
+    with pytest.raises(TypeError):
+        trainer.process(FakeModel(), [batch], fractions, loss_fn, opt, "group")   # process_group is keyword only
+
+
+def test_checkpoint_and_sample_files_are_unpickled_restrictively(tmp_path):
+    """restore_state / load_sample read files from disk: only NumPy arrays in builtin containers may come out of them."""
+    import gzip
+    import io
+    import pickle
+    from gcnn_cut_selector_amd import _safe_pickle
+    buf = io.BytesIO()
+    arrays = [np.arange(12, dtype=np.float32).reshape(3, 4), np.float32(2.5) * np.ones(1, np.float32)]
+    for a in arrays:                                        # the checkpoint format: consecutive bare records (model.py:53-56)
+        pickle.dump(a, buf)
+    buf.seek(0)
+    for a in arrays:
+        got = _safe_pickle.load(buf)
+        assert got.dtype == a.dtype and np.array_equal(got, a)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+
+    with pytest.raises(pickle.UnpicklingError):
+        _safe_pickle.load(io.BytesIO(pickle.dumps(Evil())))
+    bad = str(tmp_path / "sample_evil.pkl")
+    with gzip.open(bad, "wb") as f:
+        pickle.dump({"data": [Evil(), np.zeros(1)]}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        utils.load_sample(bad)

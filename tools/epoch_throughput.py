@@ -55,10 +55,10 @@ def main():
     for kind in ("files", "host", "store"):
         m = GCNN(device=dev)
         opt = Adam(learning_rate=lambda: 1e-3)
-        process(m, list(feed(kind))[:2], fractions, opt)      # warm-up
+        process(m, list(feed(kind))[:2], fractions, None, opt)      # warm-up
         torch.cuda.synchronize()
         t = time.perf_counter()
-        loss, acc = process(m, feed(kind), fractions, opt)
+        loss, acc = process(m, feed(kind), fractions, None, opt)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         print(f"{kind:6s}: {n_batches} batches in {dt * 1e3:8.1f} ms = {dt / n_batches * 1e3:7.3f} ms/batch, "

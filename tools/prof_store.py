@@ -10,8 +10,8 @@ store = SampleStore.from_samples(samples, dev)
 m = GCNN(device=dev); opt = Adam(learning_rate=lambda: 1e-3)
 ids = np.random.default_rng(0).choice(64, 100 * 32)
 fr = np.array([.25, .5, .75, 1.0])
-process(m, store.batches(ids[:64], 32), fr, opt); torch.cuda.synchronize()
+process(m, store.batches(ids[:64], 32), fr, None, opt); torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
-process(m, store.batches(ids, 32), fr, opt); torch.cuda.synchronize()
+process(m, store.batches(ids, 32), fr, None, opt); torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
