@@ -6,9 +6,9 @@ indset-750 x 64.
   * capfac at its real instance size (10,201 rows of length {2, 100, 101} per sample: SLOTS = 1 edge kernels, hub rows,
     650 k-row row programs) forward AND backward against the oracle, at a batch that also reaches the scaled weight-gradient
     chunks (rows_per_wave > WG_ROWS in gcnn_backward);
-  * at the full batch sizes, where an fp64 autograd oracle would need tens of GB: size-independent properties --
-    determinism, disjoint-union batching invariance, finite gradients, linearity in d_scores, and additivity of the
-    SUM-loss gradient over sample shards (each shard small enough to be pinned to the oracle by the tests above).
+  * at the full batch sizes: loss and all 46 gradients against the fp64 autograd oracle, and size-independent properties
+    -- determinism, disjoint-union batching invariance, finite gradients, linearity in d_scores, additivity of the SUM-loss
+    gradient over sample shards.
 Tolerances: scores 1e-4 absolute/relative (BASELINE.json north star); gradients as in tests/test_gpu_model.py."""
 import numpy as np
 import pytest
