@@ -68,18 +68,20 @@ static LinArgs lin_bwd(const float* dy, const float* ymask, const float* wa, flo
     return a;
 }
 
+// 16*SLOTS lanes serve one segment.  Measured on setcov-500 x 32 (tools/micro/bench_edge.hip): mean degree 50 runs best with a
+// whole wave per segment, mean degree 25 with two to four segments per wave.
 static inline int edge_slots(int n_own, int n_edges) {
     const double avg = (double)n_edges / (double)std::max(n_own, 1);
-    return avg >= 12.0 ? 4 : (avg >= 5.0 ? 2 : 1);
+    return avg >= 40.0 ? 4 : (avg >= 12.0 ? 2 : 1);
 }
-// forward (owner = receiver); `save` also emits the ReLU nibbles and the N rows for the backward pass
-static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool save, hipStream_t st) {
-    if (a.n_recv <= 0) return 0;
-    if (save && (!a.cnt_rows || (n_edges > 0 && !a.mask))) return GCNN_E_BADARG;
-    const int slots = edge_slots(a.n_recv, n_edges);
-    const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
+// forward (owner = receiver); `count` also emits the N rows (active edges per receiver and channel) for the backward pass
+static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool count, hipStream_t st) {
+    if (a.n_own <= 0) return 0;
+    if (count && !a.cnt_rows) return GCNN_E_BADARG;
+    const int slots = edge_slots(a.n_own, n_edges);
+    const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
 #define EDGE_LAUNCH(S, V) hipLaunchKernelGGL((k_edge_fwd<S, V>), dim3(grid), dim3(256), 0, st, a)
-    if (save) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
+    if (count) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
     else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
 #undef EDGE_LAUNCH
     LAUNCHCHK();
@@ -87,9 +89,9 @@ static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool save, hipStream_
 }
 // backward, sender-ordered (owner = sender)
 static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, hipStream_t st) {
-    if (a.n_recv <= 0) return 0;
-    const int slots = edge_slots(a.n_recv, n_edges);
-    const int grid = std::min(cdiv(cdiv(a.n_recv, 4 / slots), 4), MAX_GRID);
+    if (a.n_own <= 0) return 0;
+    const int slots = edge_slots(a.n_own, n_edges);
+    const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
     if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
     else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
@@ -107,7 +109,6 @@ struct Work {
     Acts a, g;            // activations and their gradients
     float* partial;       // weight-gradient slabs
     float* q[3];          // per-sender shares of d w_edge, one [n_send,64] matrix per convolution
-    unsigned long long* mask[3];  // ReLU bits of the three edge passes, 8 bytes per edge, receiver order
     float* nrow[3];          // per receiver and channel: number of active edges
     float* emb_partial[3];
     float* score_partial; int score_nblk;
@@ -141,8 +142,6 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     const size_t nrecv[3] = {C, V, K};
     const size_t nsend[3] = {V, C, V};
     for (int i = 0; i < 3; ++i) { w->q[i] = take(nsend[i] * EMB); w->nrow[i] = take(nrecv[i] * EMB); }
-    const size_t nedge[3] = {(size_t)d->n_cons_edges, (size_t)d->n_cons_edges, (size_t)d->n_cut_edges};
-    for (int i = 0; i < 3; ++i) w->mask[i] = (unsigned long long*)take(2 * nedge[i]);
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
@@ -158,7 +157,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 6; }
+int gcnn_abi_version(void) { return 7; }
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -180,13 +179,13 @@ size_t gcnn_workspace_floats(const gcnn_dims* dims) {
 // ---- graph plan -------------------------------------------------------------------------------------------------
 static size_t sort_temp_bytes(int n) {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr,
-                                       (int*)nullptr, n > 0 ? n : 1);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                    (unsigned)(n > 0 ? n : 1), 0u, 32u, (hipStream_t)0);
     return (bytes + 255) & ~(size_t)255;
 }
 size_t gcnn_graph_temp_bytes(int32_t n_edges) {
     const size_t e = ((size_t)(n_edges > 0 ? n_edges : 1) * sizeof(int) + 255) & ~(size_t)255;
-    return sort_temp_bytes(n_edges) + 5 * e;  // cub temp + iota + sorted keys + two permutations + one inverse
+    return sort_temp_bytes(n_edges) + 3 * e;  // radix-sort temp + iota + sorted keys + one permutation
 }
 
 // One launch gathers every array of a mini-batch out of a device-resident sample store (see k_collate)
@@ -224,8 +223,7 @@ int gcnn_graph_check(const int32_t* edge_inds, int32_t n_edges, int32_t n_left, 
 
 int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left, int32_t n_var,
                      int32_t left_sorted, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
-                     float* v_coef, int32_t* l2v, int32_t* v2l, int32_t* l_perm, void* temp, size_t temp_bytes,
-                     void* stream) {
+                     float* v_coef, int32_t* l_perm, void* temp, size_t temp_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_edges < 0 || n_left < 0 || n_var < 0 || !l_ptr || !v_ptr) return GCNN_E_BADARG;
     if (temp_bytes < gcnn_graph_temp_bytes(n_edges)) return GCNN_E_WORKSPACE;
@@ -236,13 +234,12 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
     }
     if (!edge_inds || !edge_feats || !l_oth || !l_coef || !v_oth || !v_coef || !temp) return GCNN_E_BADARG;
     const size_t e = ((size_t)n_edges * sizeof(int) + 255) & ~(size_t)255;
-    size_t cub_bytes = sort_temp_bytes(n_edges);
+    size_t sort_bytes = sort_temp_bytes(n_edges);
     char* t = (char*)temp;
-    void* cub_tmp = t;
-    int* iota = (int*)(t + cub_bytes);
-    int* keys = (int*)(t + cub_bytes + e);
-    int* perm[2] = {(int*)(t + cub_bytes + 2 * e), (int*)(t + cub_bytes + 3 * e)};
-    int* inv = (int*)(t + cub_bytes + 4 * e);
+    void* sort_tmp = t;
+    int* iota = (int*)(t + sort_bytes);
+    int* keys = (int*)(t + sort_bytes + e);
+    int* perm = (int*)(t + sort_bytes + 2 * e);
     const int grid = std::min(cdiv(n_edges + 1, 256), 4096);
     const int* left = edge_inds;
     const int* var = edge_inds + n_edges;
@@ -257,35 +254,19 @@ int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t 
             LAUNCHCHK();
             HIPCHK(hipMemcpyAsync(l_oth, var, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemcpyAsync(l_coef, edge_feats, (size_t)n_edges * sizeof(float), hipMemcpyDeviceToDevice, st));
-            perm[0] = iota;
+            if (l_perm) HIPCHK(hipMemcpyAsync(l_perm, iota, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
             continue;
         }
-        int bits = 1;
+        unsigned bits = 1;
         while ((1ll << bits) < (long long)nseg + 1 && bits < 31) ++bits;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(cub_tmp, cub_bytes, key_in, keys, (const int*)iota, perm[side], n_edges,
-                                                  0, bits, st));
+        // stable LSD radix sort of (node id, input position): ties keep the input order => every sum has a fixed order
+        HIPCHK(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, key_in, keys, (const int*)iota, perm, (unsigned)n_edges, 0u, bits, st));
         hipLaunchKernelGGL(k_seg_offsets, dim3(grid), dim3(256), 0, st, keys, n_edges, nseg, side == 0 ? l_ptr : v_ptr);
         LAUNCHCHK();
-        hipLaunchKernelGGL(k_gather_edges, dim3(grid), dim3(256), 0, st, perm[side], side == 0 ? var : left, edge_feats,
+        hipLaunchKernelGGL(k_gather_edges, dim3(grid), dim3(256), 0, st, perm, side == 0 ? var : left, edge_feats,
                            n_edges, side == 0 ? l_oth : v_oth, side == 0 ? l_coef : v_coef);
         LAUNCHCHK();
-    }
-    if (l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm[0], (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
-    if (v2l) {  // by-variable position -> by-left position of the same edge
-        if (left_sorted) {
-            HIPCHK(hipMemcpyAsync(v2l, perm[1], (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
-        } else {
-            hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[0], n_edges, inv); LAUNCHCHK();
-            hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[1], inv, n_edges, v2l); LAUNCHCHK();
-        }
-    }
-    if (l2v) {
-        hipLaunchKernelGGL(k_invert_perm, dim3(grid), dim3(256), 0, st, perm[1], n_edges, inv); LAUNCHCHK();
-        if (left_sorted) {
-            HIPCHK(hipMemcpyAsync(l2v, inv, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
-        } else {
-            hipLaunchKernelGGL(k_compose_perm, dim3(grid), dim3(256), 0, st, perm[0], inv, n_edges, l2v); LAUNCHCHK();
-        }
+        if (side == 0 && l_perm) HIPCHK(hipMemcpyAsync(l_perm, perm, (size_t)n_edges * sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     return 0;
 }
@@ -329,15 +310,14 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
 }
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
-                       const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out, float* n_rows, void* stream) {
+                       const float* e_scale, const float* s1, float* s_out, float* n_rows, void* stream) {
     if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
-    const bool save = mask_out || n_rows;
     EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_recv = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
-    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.mask = (unsigned long long*)mask_out; e.cnt_rows = n_rows; e.n_recv = n_recv;
-    return launch_edge_fwd(e, n_edges, save, (hipStream_t)stream);
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_own = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.cnt_rows = n_rows; e.n_own = n_recv;
+    return launch_edge_fwd(e, n_edges, n_rows != nullptr, (hipStream_t)stream);
 }
 int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
                             void* stream) {
@@ -348,39 +328,45 @@ int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* 
     LAUNCHCHK();
     return 0;
 }
-int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
-                            const uint64_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send, int32_t n_edges,
+                            const float* p_send, const float* p_recv, const float* w_edge, const float* e_shift,
                             const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
                             void* stream) {
     if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
-    if (n_send > 0 && (!seg_ptr || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
-    if (n_edges > 0 && (!oth || !coef || !xpos || !mask || !d_s)) return GCNN_E_BADARG;
+    if (n_send > 0 && (!seg_ptr || !p_send || !w_edge || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
+    if (n_edges > 0 && (!oth || !coef || !p_recv || !d_s)) return GCNN_E_BADARG;
     EdgeArgs e; memset(&e, 0, sizeof(e));
-    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.xpos = xpos; e.mask = (unsigned long long*)mask; e.s1 = s1;
-    e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_recv = n_send;
+    e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_own = p_send; e.p_oth = p_recv; e.w_edge = w_edge; e.s1 = s1;
+    e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_own = n_send;
     return launch_edge_bwd_send(e, n_edges, (hipStream_t)stream);
 }
 
 }  // extern "C"
 
 // ---- row programs: host-side launchers ---------------------------------------------------------------------------------
-// Blocks per program of a grouped launch.  One block per CU (the staged weights fill most of the LDS); 8 waves per block
-// once there is more than one tile per wave, so two waves share each SIMD's MFMA pipe and hide each other's loads.
-// One tile per wave when everything fits into 256 blocks, else 256 blocks split by work (tiles x stages).
+// Blocks per program of a grouped launch.  One block per CU (the staged weights fill most of the LDS); its 4 or 8 waves share
+// them (8 = two per SIMD, covering each other's loads and epilogues, once there is more than one tile per SIMD).  Tiles are
+// dealt round-robin over a program's blocks and then over a block's waves (k_rows.hpp), so every SIMD of every block gets
+// the same number of tiles +-1.  Row sets too small for 256 full blocks still spread over all CUs; otherwise 256 blocks
+// split by work (tiles x stages).  (16 waves per block, four per SIMD, were measured and rejected: profiles/README.md.)
 static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) {
     int ntile[3], total = 0;
     for (int i = 0; i < ngroups; ++i) { ntile[i] = n[i] > 0 ? cdiv(n[i], 16) : 0; total += ntile[i]; }
-    const int nwaves = total > 1024 ? 8 : 4;
+    static const int forced = getenv("GCNN_ROWS_WAVES") ? atoi(getenv("GCNN_ROWS_WAVES")) : 0;   // tuning knob (tools/README.md)
+    const int nwaves = (forced == 4 || forced == 8) ? forced : (total > 1024 ? 8 : 4);
     int want[3], sum_want = 0;
     long long work[3], sum_work = 0;
     for (int i = 0; i < ngroups; ++i) {
         want[i] = cdiv(ntile[i], nwaves); sum_want += want[i];
         work[i] = (long long)ntile[i] * nstage[i]; sum_work += work[i];
     }
+    // fewer than 256 blocks of this size: spread the tiles over all CUs instead (fewer tiles per block, idle waves are free)
+    const bool spread = sum_want < 256 && total > 1024;
     blk0[0] = 0;
     for (int i = 0; i < ngroups; ++i) {
         int nb = want[i];
-        if (sum_want > 256 && nb > 0) nb = std::max(1, std::min(want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
+        if ((sum_want > 256 || spread) && nb > 0)
+            nb = std::max(1, std::min(spread ? ntile[i] : want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
         blk0[i + 1] = blk0[i] + nb;
     }
     return nwaves;
@@ -438,16 +424,16 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
     float *PL, *PR, *S, *A, *Z1, *OUT;
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
-    unsigned long long* mask; float* N;
+    float* N;
 };
 
 static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
     EdgeArgs e; memset(&e, 0, sizeof(e));
     e.seg_ptr = by_left ? c.g->l_ptr : c.g->v_ptr; e.oth = by_left ? c.g->l_oth : c.g->v_oth;
     e.coef = by_left ? c.g->l_coef : c.g->v_coef;
-    e.p_recv = by_left ? c.PL : c.PR; e.p_oth = by_left ? c.PR : c.PL;   // segment owner's table / gathered table
+    e.p_own = by_left ? c.PL : c.PR; e.p_oth = by_left ? c.PR : c.PL;   // segment owner's table / gathered table
     e.w_edge = p + poff(c.pbase + C_WE); e.e_shift = p + poff(c.pedge); e.e_scale = p + poff(c.pedge + 1);
-    e.s1 = p + poff(c.pbase + C_S1); e.n_recv = by_left ? c.nl : c.nv;
+    e.s1 = p + poff(c.pbase + C_S1); e.n_own = by_left ? c.nl : c.nv;
     return e;
 }
 
@@ -458,7 +444,7 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
                         float* t_out, int tail, float* scores, const LossHead* head) {
     int rc;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
-    e.out = c.S; e.mask = c.mask; e.cnt_rows = c.N;
+    e.out = c.S; e.cnt_rows = c.N;
     if ((rc = launch_edge_fwd(e, c.ne, save, st))) return rc;
     ConvFArgs a; memset(&a, 0, sizeof(a));
     a.n = c.recv_left ? c.nl : c.nv;
@@ -476,11 +462,11 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.mask[0], w.nrow[0]};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.nrow[0]};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.mask[1], w.nrow[1]};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.nrow[1]};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.mask[2], w.nrow[2]};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.nrow[2]};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -596,10 +582,10 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     int rc;
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
-    // the receiver-ordered half (dP_recv) came out of the row program's epilogue; sender-ordered half: dS rows + 8-B masks,
-    // which also yields Q, the per-sender share of d w_edge
+    // the receiver-ordered half (dP_recv) came out of the row program's epilogue; sender-ordered half: gathers dS and P_recv rows
+    // (the ReLU pattern is recomputed), which also yields Q, the per-sender share of d w_edge
     EdgeArgs e = conv_edge_args(p, c, !c.recv_left);
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q; e.mask = c.mask; e.xpos = c.recv_left ? c.g->v2l : c.g->l2v;
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q;
     if ((rc = launch_edge_bwd_send(e, c.ne, st))) return rc;
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
     float* gwe = grads + poff(c.pbase + C_WE);

@@ -1,7 +1,7 @@
 // gcnn_common.hpp -- shared definitions: parameter layout, MFMA wrappers, small device helpers.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>

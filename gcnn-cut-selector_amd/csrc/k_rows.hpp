@@ -183,7 +183,7 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
     float* w1s = smem + ROWS_LDS_FLOATS(NM, NV);   // first-layer kernel [F][64], bias b1 in vecs[0]
-    int tile = bid * NWAVES + wv;
+    int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
     float xv[F];
     auto load_ops = [&](int t) {
         const int row = t * 16 + j;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
-    int tile = bid * NWAVES + wv;
+    int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
     RTile s_in, xr;
     int seg0 = 0, seg1 = 0;
     auto load_ops = [&](int t) {
@@ -402,7 +402,7 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
     constexpr int NWAVES = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
-    int tile = bid * NWAVES + wv;
+    int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
     RTile in, m0, m1, nr;
     auto load_ops = [&](int t) {
         const int row = t * 16 + j;
@@ -465,7 +465,7 @@ __device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, i
     constexpr int NWAVES = NT / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
-    int tile = bid * NWAVES + wv;
+    int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
     RTile ia, ib, ad, mk;
     auto load_ops = [&](int t) {
         const int row = t * 16 + j;

@@ -3,7 +3,7 @@
 The reference feeds `tf.gather` / `tf.scatter_nd` a raw COO list (/root/reference/model.py:564-569).  Here the COO
 list is turned ONCE per batch into receiver-sorted CSR in both orders (by left node and by variable), so that the
 scatter-sum and every gradient of the gathers run as atomic-free segmented sums (gcnn_graph_build in
-include/gcnn_hip.h)."""
+include/gcnn_hip.h).  The two orders are independent lists: no pass needs to find an edge of one order in the other."""
 
 from __future__ import annotations
 
@@ -63,27 +63,24 @@ class BipartiteGraph:
         self.v_oth = torch.empty(n_edges, **i32)
         self.l_coef = torch.empty(n_edges, **f32)
         self.v_coef = torch.empty(n_edges, **f32)
-        self.l2v = torch.empty(n_edges, **i32)   # by-left position -> by-variable position of the same edge
-        self.v2l = torch.empty(n_edges, **i32)
         self.l_perm = torch.empty(n_edges, **i32) if keep_perm else None
         temp_bytes = lib.gcnn_graph_temp_bytes(n_edges)
         temp = torch.empty(temp_bytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _lib.check(lib.gcnn_graph_build(_ptr(edge_inds), _ptr(edge_feats), n_edges, n_left, n_var, left_sorted,
                                             _ptr(self.l_ptr), _ptr(self.l_oth), _ptr(self.l_coef), _ptr(self.v_ptr),
-                                            _ptr(self.v_oth), _ptr(self.v_coef), _ptr(self.l2v), _ptr(self.v2l),
-                                            _ptr(self.l_perm), _ptr(temp),
+                                            _ptr(self.v_oth), _ptr(self.v_coef), _ptr(self.l_perm), _ptr(temp),
                                             temp_bytes, _stream(dev)), "gcnn_graph_build")
         # keep the temp alive until the stream has consumed it
         temp.record_stream(torch.cuda.current_stream(dev))
         self._bind()
 
     @classmethod
-    def from_plan(cls, n_left, n_var, l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef, l2v, v2l):
+    def from_plan(cls, n_left, n_var, l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef):
         """Wrap CSR arrays that already exist on the device (SampleStore.batch collates them; no sort runs)."""
         g = cls.__new__(cls)
         g.n_edges, g.n_left, g.n_var, g.device = int(l_oth.numel()), int(n_left), int(n_var), l_ptr.device
-        g.l_ptr, g.l_oth, g.l_coef, g.v_ptr, g.v_oth, g.v_coef, g.l2v, g.v2l = l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef, l2v, v2l
+        g.l_ptr, g.l_oth, g.l_coef, g.v_ptr, g.v_oth, g.v_coef = l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef
         g.l_perm = None
         g._bind()
         return g
@@ -92,5 +89,4 @@ class BipartiteGraph:
         n_edges = self.n_edges
         self.c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
                             self.l_coef.data_ptr() if n_edges else 0, self.v_ptr.data_ptr(),
-                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0,
-                            self.l2v.data_ptr() if n_edges else 0, self.v2l.data_ptr() if n_edges else 0)
+                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0)

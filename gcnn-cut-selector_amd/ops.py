@@ -55,36 +55,35 @@ def _edge_side(graph: BipartiteGraph, by_left: bool):
 
 def conv_edge_fwd(graph: BipartiteGraph, recv_is_left: bool, pl, pr, w_edge, e_shift, e_scale, s1, save=False):
     """S[r] = sum_e relu(s1*(PL[l_e] + c_e*w + PR[v_e])) over the receiver's segment (gcnn_conv_edge_fwd).
-    With save=True returns (S, saved) where saved = (mask[E] int64, N[R,64]) is what conv_edge_bwd consumes."""
+    With save=True returns (S, N) where N[R,64] (active edges per receiver and channel) is what conv_edge_bwd consumes."""
     ptr, oth, coef, n_recv = _edge_side(graph, recv_is_left)
     p_recv, p_oth = (pl, pr) if recv_is_left else (pr, pl)
     dev = pl.device
     out = torch.empty((n_recv, EMB), dtype=torch.float32, device=dev)
-    mask = torch.empty(graph.n_edges, dtype=torch.int64, device=dev) if save else None
     nrows = torch.empty((n_recv, EMB), dtype=torch.float32, device=dev) if save else None
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().gcnn_conv_edge_fwd(_ptr(ptr), _ptr(oth), _ptr(coef), n_recv, graph.n_edges, _ptr(p_recv),
                                                  _ptr(p_oth), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale), _ptr(s1),
-                                                 _ptr(out), _ptr(mask), _ptr(nrows), _stream(dev)), "gcnn_conv_edge_fwd")
-    return (out, (mask, nrows)) if save else out
+                                                 _ptr(out), _ptr(nrows), _stream(dev)), "gcnn_conv_edge_fwd")
+    return (out, nrows) if save else out
 
 
-def conv_edge_bwd(graph: BipartiteGraph, recv_is_left: bool, saved, e_shift, e_scale, s1, d_s):
-    """Gradients of the edge pass from what the forward saved: (d_PL, d_PR, d_w_edge[64])."""
+def conv_edge_bwd(graph: BipartiteGraph, recv_is_left: bool, nrows, pl, pr, w_edge, e_shift, e_scale, s1, d_s):
+    """Gradients of the edge pass: (d_PL, d_PR, d_w_edge[64]).  The receiver side uses the N rows of the forward; the sender
+    side recomputes the ReLU pattern from the projected tables PL / PR (nothing per edge was stored)."""
     lib = _lib.lib()
     dev = d_s.device
-    mask, nrows = saved
     n_recv = graph.n_left if recv_is_left else graph.n_var
     d_recv = torch.empty((n_recv, EMB), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.gcnn_conv_edge_bwd_recv(_ptr(d_s), _ptr(nrows), _ptr(s1), n_recv, _ptr(d_recv), _stream(dev)),
                    "gcnn_conv_edge_bwd_recv")
         sptr, soth, scoef, n_send = _edge_side(graph, not recv_is_left)
-        xpos = graph.v2l if recv_is_left else graph.l2v
+        p_send, p_recv = (pr, pl) if recv_is_left else (pl, pr)
         d_send = torch.empty((n_send, EMB), dtype=torch.float32, device=dev)
         rows = torch.zeros((max(n_send, 1), EMB), dtype=torch.float32, device=dev)  # per-sender shares of d w_edge
-        _lib.check(lib.gcnn_conv_edge_bwd_send(_ptr(sptr), _ptr(soth), _ptr(scoef), _ptr(xpos), _ptr(mask), n_send,
-                                               graph.n_edges, _ptr(e_shift), _ptr(e_scale), _ptr(s1), _ptr(d_s),
+        _lib.check(lib.gcnn_conv_edge_bwd_send(_ptr(sptr), _ptr(soth), _ptr(scoef), n_send, graph.n_edges, _ptr(p_send),
+                                               _ptr(p_recv), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale), _ptr(s1), _ptr(d_s),
                                                _ptr(d_send), _ptr(rows), _stream(dev)), "gcnn_conv_edge_bwd_send")
     d_pl, d_pr = (d_recv, d_send) if recv_is_left else (d_send, d_recv)
     return d_pl, d_pr, rows.sum(0)

@@ -25,7 +25,7 @@ from .model import Batch
 StoreBatch = namedtuple("StoreBatch", "batch n_cons n_vars n_cuts improvements")
 
 _K_CONS, _K_VAR, _K_CUT, _K_E1, _K_E2 = range(5)   # unit kinds: which offset table indexes an array
-_GRAPH_FIELDS = ("l_ptr", "l_oth", "l_coef", "v_ptr", "v_oth", "v_coef", "l2v", "v2l")
+_GRAPH_FIELDS = ("l_ptr", "l_oth", "l_coef", "v_ptr", "v_oth", "v_coef")
 
 
 def _localise(graph: BipartiteGraph, n_left, n_var, n_edge, dev):
@@ -35,13 +35,11 @@ def _localise(graph: BipartiteGraph, n_left, n_var, n_edge, dev):
     first = lambda n: torch.cumsum(n, 0) - n
     of_left = torch.repeat_interleave(first(n_edge), n_left)    # edge offset of the sample each left row belongs to
     of_var = torch.repeat_interleave(first(n_edge), n_var)
-    edge_e = torch.repeat_interleave(first(n_edge), n_edge)     # per edge (either order: samples are contiguous in both)
     edge_l = torch.repeat_interleave(first(n_left), n_edge)
     edge_v = torch.repeat_interleave(first(n_var), n_edge)
     i32 = torch.int32
     return dict(l_ptr=(graph.l_ptr[:-1] - of_left).to(i32), l_oth=(graph.l_oth - edge_v).to(i32), l_coef=graph.l_coef,
-                v_ptr=(graph.v_ptr[:-1] - of_var).to(i32), v_oth=(graph.v_oth - edge_l).to(i32), v_coef=graph.v_coef,
-                l2v=(graph.l2v - edge_e).to(i32), v2l=(graph.v2l - edge_e).to(i32))
+                v_ptr=(graph.v_ptr[:-1] - of_var).to(i32), v_oth=(graph.v_oth - edge_l).to(i32), v_coef=graph.v_coef)
 
 
 class SampleStore:
@@ -175,18 +173,18 @@ class SampleStore:
         n_c, n_v, n_k, n_e1, n_e2 = (int(x) for x in dst[:, -1])
         if max(n_c, n_v, n_k, n_e1, n_e2) >= 2 ** 31 - 1:
             raise ValueError("batch too large for int32 indices")
-        # one allocation carved into the 20 arrays of the batch (64-word aligned)
+        # one allocation carved into the 16 arrays of the batch (64-word aligned)
         spec = [("cons_feats", n_c * 4), ("var_feats", n_v * 14), ("cut_feats", n_k * 6), ("improvements", n_k)]
         for slot, (nl, ne) in enumerate(((n_c, n_e1), (n_k, n_e2))):
             spec += [(f"{slot}.l_ptr", nl + 1), (f"{slot}.l_oth", ne), (f"{slot}.l_coef", ne), (f"{slot}.v_ptr", n_v + 1),
-                     (f"{slot}.v_oth", ne), (f"{slot}.v_coef", ne), (f"{slot}.l2v", ne), (f"{slot}.v2l", ne)]
+                     (f"{slot}.v_oth", ne), (f"{slot}.v_coef", ne)]
         pos, total = {}, 0
         for name, n in spec:
             pos[name] = (total, n)
             total += (n + 63) & ~63
         buf = torch.empty(max(total, 64), dtype=torch.int32, device=dev)
         view = lambda name: buf[pos[name][0]:pos[name][0] + pos[name][1]]
-        jobs = (_lib.CollateJob * 20)()
+        jobs = (_lib.CollateJob * 16)()
         nj = 0
 
         def job(src, name, kind, width, add=-1, is_ptr=0):
@@ -206,8 +204,6 @@ class SampleStore:
             job(g["v_ptr"], f"{slot}.v_ptr", _K_VAR, 1, ke, 1)
             job(g["v_oth"], f"{slot}.v_oth", ke, 1, kl)
             job(g["v_coef"], f"{slot}.v_coef", ke, 1)
-            job(g["l2v"], f"{slot}.l2v", ke, 1, ke)
-            job(g["v2l"], f"{slot}.v2l", ke, 1, ke)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().gcnn_collate(jobs, nj, C.c_void_p(tab.data_ptr()), C.c_void_p(tab.data_ptr() + 8 * 5 * b),
                                                b, max(n for _, n in spec), _stream(dev)), "gcnn_collate")
@@ -217,7 +213,7 @@ class SampleStore:
         for slot, nl in enumerate((n_c, n_k)):
             graphs.append(BipartiteGraph.from_plan(
                 nl, n_v, view(f"{slot}.l_ptr"), view(f"{slot}.l_oth"), f32(f"{slot}.l_coef", -1), view(f"{slot}.v_ptr"),
-                view(f"{slot}.v_oth"), f32(f"{slot}.v_coef", -1), view(f"{slot}.l2v"), view(f"{slot}.v2l")))
+                view(f"{slot}.v_oth"), f32(f"{slot}.v_coef", -1)))
         batch = Batch(f32("cons_feats", n_c, 4), f32("var_feats", n_v, 14), f32("cut_feats", n_k, 6), graphs[0], graphs[1])
         sizes = self.sizes[:, ids]
         return StoreBatch(batch, sizes[_K_CONS].astype(np.int32), sizes[_K_VAR].astype(np.int32),
@@ -227,7 +223,7 @@ class SampleStore:
         dev = self.device
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
-        graph = lambda: BipartiteGraph.from_plan(0, 0, i32(1), i32(0), f32(0), i32(1), i32(0), f32(0), i32(0), i32(0))
+        graph = lambda: BipartiteGraph.from_plan(0, 0, i32(1), i32(0), f32(0), i32(1), i32(0), f32(0))
         z = np.zeros(0, np.int32)
         return StoreBatch(Batch(f32(0, 4), f32(0, 14), f32(0, 6), graph(), graph()), z, z, z, f32(0))
 

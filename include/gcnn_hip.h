@@ -46,8 +46,6 @@ typedef struct gcnn_graph {
     const int32_t* v_ptr;   /* [n_var+1]   segment offsets, edges grouped by variable node */
     const int32_t* v_oth;   /* [E]         left index of each edge, by-variable order */
     const float*   v_coef;  /* [E]         raw edge feature, by-variable order */
-    const int32_t* l2v;     /* [E]         by-left position -> by-variable position of the same edge */
-    const int32_t* v2l;     /* [E]         by-variable position -> by-left position of the same edge */
 } gcnn_graph;
 
 /* ---- graph plan: COO -> receiver-sorted CSR in both orders -------------------------------------------------
@@ -63,9 +61,8 @@ int gcnn_graph_check(const int32_t* edge_inds, int32_t n_edges, int32_t n_left, 
  * utils.py:102-104) skips the by-left sort: the by-left order is then the input order. */
 int gcnn_graph_build(const int32_t* edge_inds, const float* edge_feats, int32_t n_edges, int32_t n_left,
                      int32_t n_var, int32_t left_sorted, int32_t* l_ptr, int32_t* l_oth, float* l_coef, int32_t* v_ptr, int32_t* v_oth,
-                     float* v_coef, int32_t* l2v /* optional */, int32_t* v2l /* optional */,
-                     int32_t* l_perm /* optional [E]: by-left position -> input edge id */, void* temp, size_t temp_bytes,
-                     void* stream);
+                     float* v_coef, int32_t* l_perm /* optional [E]: by-left position -> input edge id */, void* temp,
+                     size_t temp_bytes, void* stream);
 
 /* ---- device-side batch collation: utils.load_batch's stacking (utils.py:389-426) on a device-resident sample store
  * The store keeps every sample's arrays (features, targets and both CSR orders of both edge sets) concatenated in
@@ -110,29 +107,28 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  * forward:  s_out[r] = sum_{e in seg(r)} relu(s1 * (PL[l_e] + c_e*w_edge + PR[v_e])),  c_e = (coef_e+e_shift)*e_scale
  *           p_recv = projected table of the receiving side [n_recv,64] (constraint/cut side when from_v=True,
  *           model.py:553-556), p_oth = the other side's table, gathered by oth[e].
- *           Optional outputs for the backward pass (both or none): mask_out [E] uint64 in receiver order, nibble c of
- *           word e holds the bits [s1*J_e > 0] of channels 4c..4c+3; n_rows [n_recv,64] = number of active edges per
- *           receiver and channel.
+ *           Optional output for the backward pass: n_rows [n_recv,64] = number of active edges ([s1*J_e > 0]) per
+ *           receiver and channel.  Nothing is stored per edge.
  * bwd_recv: element-wise, because d_s[r] is constant over a segment: d_p_recv = s1*d_s*n_rows.
- * bwd_send: segments grouped by the SENDING node; with t_e = mask[xpos[e]] * d_s[oth[e]]:
+ * bwd_send: segments grouped by the SENDING node u; the ReLU pattern is recomputed from the two projected tables with the
+ *           forward's own expression (bit-identical): with r = oth[e], J_e = (c_e*w_edge + p_send[u]) + p_recv[r] and
+ *           t_e = [s1*J_e > 0] * d_s[r]:
  *           d_p_send[u] = s1*sum_{e in seg(u)} t_e ;  dw_rows[u] = s1*sum_{e in seg(u)} c_e*t_e  (its column sum is the
- *           gradient of feature_module_edge's kernel, model.py:490-492);
- *           xpos[e] = position of edge e in the receiver-ordered list (gcnn_graph.l2v / v2l). */
+ *           gradient of feature_module_edge's kernel, model.py:490-492). */
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
-                       const float* e_scale, const float* s1, float* s_out, uint64_t* mask_out, float* n_rows,
-                       void* stream);
+                       const float* e_scale, const float* s1, float* s_out, float* n_rows /* optional */, void* stream);
 int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
                             void* stream);
-int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, const int32_t* xpos,
-                            const uint64_t* mask, int32_t n_send, int32_t n_edges, const float* e_shift,
+int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send, int32_t n_edges,
+                            const float* p_send, const float* p_recv, const float* w_edge, const float* e_shift,
                             const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
                             void* stream);
 
 /* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
  * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied
  * inside, model.py:365-382).  workspace: gcnn_workspace_floats(dims) floats.  save_for_backward != 0 leaves the
- * activations, ReLU masks and edge statistics gcnn_backward needs in the workspace; 0 (inference) skips those stores.
+ * activations and edge statistics (the N rows) gcnn_backward needs in the workspace; 0 (inference) skips those stores.
  * scores: [n_cuts] (model.py:300). */
 size_t gcnn_workspace_floats(const gcnn_dims* dims);
 int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 from gcnn_cut_selector_amd import synthetic, utils  # noqa: E402
 from oracle import gcnn_oracle as O  # noqa: E402  (checker only)
 
-GRAPH_FIELDS = ("l_ptr", "l_oth", "l_coef", "v_ptr", "v_oth", "v_coef", "l2v", "v2l")
+GRAPH_FIELDS = ("l_ptr", "l_oth", "l_coef", "v_ptr", "v_oth", "v_coef")
 
 
 @pytest.fixture(scope="module")

@@ -142,7 +142,7 @@ def test_full_size_batching_invariance_determinism_and_finite_grads(dev):
     flat = m.flat_parameters.detach()
     scores = m._forward_into(flat, batch, ws)
     d = torch.randn_like(scores)
-    ga, gb = torch.empty_like(flat), torch.empty_like(flat)
+    ga, gb = torch.zeros_like(flat), torch.zeros_like(flat)   # non-trainable / padding slots are never written
     m._backward_into(flat, batch, ws, d, ga)
     m._forward_into(flat, batch, ws)
     m._backward_into(flat, batch, ws, 2 * d, gb)
