@@ -49,6 +49,8 @@ _DP, _GP = C.POINTER(Dims), C.POINTER(Graph)
 # name -> (restype, argtypes); every symbol include/gcnn_hip.h declares
 SIGNATURES = {
     "gcnn_abi_version": (C.c_int, []),
+    "gcnn_profile_begin": (C.c_int, []),
+    "gcnn_profile_end": (C.c_int, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]),
     "gcnn_param_count": (C.c_int, []),
     "gcnn_param_total_floats": (C.c_int, []),
     "gcnn_param_info": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
@@ -99,8 +101,26 @@ def lib() -> C.CDLL:
 
 def check(rc: int, what: str):
     if rc != 0:
-        kind = {-1: "bad argument", -2: "workspace too small"}.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
+        kind = {-1: "bad argument", -2: "workspace too small", -3: "HIP call failed"}.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
         raise GcnnError(f"{what} failed: {kind}")
+
+
+class launch_profile:
+    """`with launch_profile() as prof: ...` -> prof.launches = [(kernel name, milliseconds)] of every library launch inside."""
+
+    def __enter__(self):
+        check(lib().gcnn_profile_begin(), "gcnn_profile_begin")
+        self.launches = []
+        return self
+
+    def __exit__(self, *exc):
+        cap = 512
+        names, ms = (C.c_char_p * cap)(), (C.c_float * cap)()
+        n = lib().gcnn_profile_end(cap, names, ms)
+        if n < 0:
+            check(n, "gcnn_profile_end")
+        self.launches = [(names[i].decode(), float(ms[i])) for i in range(min(n, cap))]
+        return False
 
 
 def param_layout():

@@ -40,6 +40,24 @@ struct PerDeviceOnce {
         return true;
     }
 };
+// ---- per-launch timing (gcnn_profile_begin / gcnn_profile_end): bench.py's roofline_step block -----------------------------
+// While enabled every kernel launch of the library is bracketed by two HIP events on the launch stream.  A measuring aid for
+// one thread; off by default and then a single predictable branch per launch.
+#define GCNN_PROF_MAX 512
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+static struct { bool on; int n; ProfRec rec[GCNN_PROF_MAX]; } g_prof;
+struct ProfScope {
+    hipStream_t st; bool live;
+    ProfScope(const char* name, hipStream_t s) : st(s), live(g_prof.on && g_prof.n < GCNN_PROF_MAX) {
+        if (!live) return;
+        ProfRec& r = g_prof.rec[g_prof.n];
+        r.name = name;
+        if (!r.e0 && (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess)) { live = false; return; }
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() { if (live) { (void)hipEventRecord(g_prof.rec[g_prof.n].e1, st); ++g_prof.n; } }
+};
+
 static const int LIN_SMEM = (2 * 64 * LDW + 4 * 32 * LDW) * (int)sizeof(float);  // 69,632 B
 static const int MAX_GRID = 2048;
 
@@ -80,6 +98,7 @@ static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool count, hipStream
     if (count && !a.cnt_rows) return GCNN_E_BADARG;
     const int slots = edge_slots(a.n_own, n_edges);
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
+    ProfScope prof(count ? "k_edge_fwd<count>" : "k_edge_fwd", st);
 #define EDGE_LAUNCH(S, V) hipLaunchKernelGGL((k_edge_fwd<S, V>), dim3(grid), dim3(256), 0, st, a)
     if (count) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
     else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
@@ -92,6 +111,7 @@ static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, hipStream_t st) 
     if (a.n_own <= 0) return 0;
     const int slots = edge_slots(a.n_own, n_edges);
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
+    ProfScope prof("k_edge_bwd_send", st);
     if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
     else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
@@ -158,6 +178,22 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 extern "C" {
 
 int gcnn_abi_version(void) { return 7; }
+
+int gcnn_profile_begin(void) { g_prof.n = 0; g_prof.on = true; return 0; }
+int gcnn_profile_end(int32_t capacity, const char** names, float* ms) {
+    g_prof.on = false;
+    const int n = g_prof.n;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;   // the return value is a count, so a HIP failure is reported as GCNN_E_HIP
+        if (hipEventSynchronize(g_prof.rec[i].e1) != hipSuccess || hipEventElapsedTime(&t, g_prof.rec[i].e0, g_prof.rec[i].e1) != hipSuccess) {
+            g_prof.n = 0;
+            return GCNN_E_HIP;
+        }
+        if (i < capacity) { if (names) names[i] = g_prof.rec[i].name; if (ms) ms[i] = t; }
+    }
+    g_prof.n = 0;
+    return n;
+}
 int gcnn_param_count(void) { return GCNN_N_PARAMS; }
 int gcnn_param_total_floats(void) { layout_init(); return g_ptotal; }
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable) {
@@ -371,8 +407,9 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
     }
     return nwaves;
 }
-#define ROWS_LAUNCH(KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ARGS)                                                     \
+#define ROWS_LAUNCH(NAME, KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ARGS)                                               \
     do {                                                                                                                \
+        ProfScope prof(NAME, ST);                                                                                       \
         static PerDeviceOnce attr;                                                                                      \
         if (attr.first()) {                                                                                             \
             HIPCHK(hipFuncSetAttribute((const void*)KERNEL8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
@@ -387,7 +424,7 @@ static int launch_embed_fwd(EmbGroupArgs& m, hipStream_t st) {
     const int n[3] = {m.v.n, m.c.n, m.k.n}, ns[3] = {4, 3, 3};
     const int nwaves = rows_blocks(n, ns, 3, m.blk0);
     if (m.blk0[3] == 0) return 0;
-    ROWS_LAUNCH(k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3], EMB_LDS_FLOATS * sizeof(float), st, m);
+    ROWS_LAUNCH("k_embed_fwd", k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3], EMB_LDS_FLOATS * sizeof(float), st, m);
     return 0;
 }
 static int launch_conv_fwd(const ConvFArgs& a, int tail, hipStream_t st) {
@@ -396,23 +433,23 @@ static int launch_conv_fwd(const ConvFArgs& a, int tail, hipStream_t st) {
     const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
     if (blk0[1] == 0) return 0;
     const size_t smem = ROWS_LDS_FLOATS(5, 5) * sizeof(float);
-    if (tail == CF_LOSS) ROWS_LAUNCH((k_conv_fwd<8, CF_LOSS>), (k_conv_fwd<4, CF_LOSS>), nwaves, blk0[1], smem, st, a);
-    else if (tail == CF_READOUT) ROWS_LAUNCH((k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
-    else ROWS_LAUNCH((k_conv_fwd<8, CF_PROJ>), (k_conv_fwd<4, CF_PROJ>), nwaves, blk0[1], smem, st, a);
+    if (tail == CF_LOSS) ROWS_LAUNCH("k_conv_fwd<loss>", (k_conv_fwd<8, CF_LOSS>), (k_conv_fwd<4, CF_LOSS>), nwaves, blk0[1], smem, st, a);
+    else if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout>", (k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
+    else ROWS_LAUNCH("k_conv_fwd<proj>", (k_conv_fwd<8, CF_PROJ>), (k_conv_fwd<4, CF_PROJ>), nwaves, blk0[1], smem, st, a);
     return 0;
 }
 static int launch_conv_bwd(ConvBGroupArgs& m, hipStream_t st) {
     const int n[2] = {m.cb.n, m.tail.n}, ns[2] = {5, 2};
     const int nwaves = rows_blocks(n, ns, 2, m.blk0);
     if (m.blk0[2] == 0) return 0;
-    ROWS_LAUNCH(k_conv_bwd<8>, k_conv_bwd<4>, nwaves, m.blk0[2], ROWS_LDS_FLOATS(5, 1) * sizeof(float), st, m);
+    ROWS_LAUNCH("k_conv_bwd", k_conv_bwd<8>, k_conv_bwd<4>, nwaves, m.blk0[2], ROWS_LDS_FLOATS(5, 1) * sizeof(float), st, m);
     return 0;
 }
 static int launch_tail_bwd(TailGroupArgs& m, hipStream_t st) {
     const int n[2] = {m.a.n, m.b.n}, ns[2] = {3, 2};
     const int nwaves = rows_blocks(n, ns, 2, m.blk0);
     if (m.blk0[2] == 0) return 0;
-    ROWS_LAUNCH(k_tail_bwd<8>, k_tail_bwd<4>, nwaves, m.blk0[2], ROWS_LDS_FLOATS(3, 1) * sizeof(float), st, m);
+    ROWS_LAUNCH("k_tail_bwd", k_tail_bwd<8>, k_tail_bwd<4>, nwaves, m.blk0[2], ROWS_LDS_FLOATS(3, 1) * sizeof(float), st, m);
     return 0;
 }
 
@@ -608,6 +645,7 @@ extern "C" int gcnn_mse_loss(const float* scores, const float* targets, int32_t 
         if (loss_out) HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
         return 0;
     }
+    ProfScope prof("k_mse", (hipStream_t)stream);
     hipLaunchKernelGGL(k_mse, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, targets, scale, loss_out, d_scores, n);
     LAUNCHCHK();
     return 0;
@@ -657,6 +695,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if (loss_out) add_rd(jl, w.score_partial + EMB + 1, loss_out, head_parts, HEAD_SLAB, 1);
         jl.rd.cdst = cut_count_out; jl.rd.cval = (float)d->n_cuts;
     } else {
+        ProfScope prof("k_score_bwd", st);
         hipLaunchKernelGGL(k_score_bwd, dim3(w.score_nblk), dim3(256), 0, st, d_scores, A.O1, p + poff(P_OUT + 2), G.O1,
                            w.score_partial, cut_count_out, d->n_cuts);
         LAUNCHCHK();
@@ -717,12 +756,14 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         static PerDeviceOnce attr;
         const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default
         if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ProfScope prof("k_wgrad", st);
         hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64 * WG_WAVES), smem, st, jl.wg, ea);
         LAUNCHCHK();
     }
     const bool fuse_adam = adam && d->n_cons > 0 && d->n_vars > 0 && jl.rdblk > 0;
     if (fuse_adam) jl.rd.adam = RdAdam{adam->params, adam->m, adam->v, grads, g_ptotal, adam->lr_t, adam->beta1, adam->beta2, adam->eps};
     if (jl.rdblk > 0) {
+        ProfScope prof(fuse_adam ? "k_reduce<adam>" : "k_reduce", st);
         hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
         LAUNCHCHK();
     }
@@ -782,6 +823,7 @@ extern "C" int gcnn_adam_step(float* params, const float* grads, float* m, float
                    float eps, const float* grad_scale, int32_t scale_is_divisor, void* stream) {
     if (n < 0 || (n > 0 && (!params || !grads || !m || !v))) return GCNN_E_BADARG;
     if (n == 0) return 0;
+    ProfScope prof("k_adam", (hipStream_t)stream);
     hipLaunchKernelGGL(k_adam, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
                        lr_t, beta1, beta2, eps, grad_scale, scale_is_divisor);
     LAUNCHCHK();

@@ -408,6 +408,20 @@ class GCNN:
         st["var"] = (m2 / st["count"]).astype(f)
         return True
 
+    def pretrain_sync(self, process_group):
+        """Data-parallel fitting: merge the statistics of the layer that is absorbing updates across the ranks of
+        `process_group` (every rank saw only its shard of the pretraining batches).  Call once per pass, on every rank,
+        before `pretrain_next`.  The merge is the same Chan update as between batches (model.py:415-423), in rank order."""
+        if self._prenorm_state is None or process_group is None:
+            return
+        waiting = [i for i, st in enumerate(self._prenorm_state) if st["waiting"]]
+        if not waiting:          # identical on every rank: the set of fitted layers only changes through this method's callers
+            return
+        from .parallel import allgather_prenorm
+        st = self._prenorm_state[waiting[0]]
+        st["count"], st["mean"], st["var"], st["received"] = allgather_prenorm(st["count"], st["mean"], st["var"], st["received"],
+                                                                              process_group, self.device)
+
     def pretrain_next(self):
         """BaseModel.pretrain_next (model.py:89-117): freeze the layer that just received updates
         (PreNormLayer.stop_updates, model.py:425-437: shift = -mean, scale = 1/sqrt(var), var == 0 -> 1)."""

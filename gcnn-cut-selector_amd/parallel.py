@@ -25,6 +25,46 @@ def shard_samples(sizes, world_size: int):
     return [sorted(x) for x in out]
 
 
+def chan_merge(stats):
+    """Merge streaming (count, mean, var) triples in list order with the update of PreNormLayer.update_params
+    (/root/reference/model.py:415-423; Chan et al.), in fp32 like the reference.  `stats`: iterable of (count, mean[u], var[u]);
+    triples with count 0 are skipped.  Returns (count, mean, var)."""
+    f = np.float32
+    count, mean, var = f(0), None, None
+    for c, m, v in stats:
+        c, m, v = f(c), np.asarray(m, f), np.asarray(v, f)
+        if c == 0:
+            continue
+        if mean is None:       # the reference starts from count = 0, mean = 0, var = 0 and applies the same update
+            mean, var = np.zeros_like(m), np.zeros_like(v)
+        delta = m - mean
+        m2 = var * count + v * c + delta ** 2 * count * c / (count + c)
+        count = f(count + c)
+        mean = (mean + delta * c / count).astype(f)
+        var = (m2 / count).astype(f)
+    return count, mean, var
+
+
+def allgather_prenorm(count, mean, var, received: bool, process_group, device):
+    """Data-parallel PreNorm fitting (SURVEY.md section 8e): every rank contributes the triple it accumulated over ITS batches;
+    the triples are merged in rank order, so all ranks end up with bit-identical statistics.  One small all-gather per layer.
+    Returns (count, mean, var, received_anywhere)."""
+    import torch
+    import torch.distributed as dist
+    units = len(mean)
+    vec = torch.tensor(np.concatenate([[float(received), float(count)], mean, var]).astype(np.float32))
+    on_gpu = dist.get_backend(process_group) == "nccl"
+    if on_gpu:
+        vec = vec.to(device)
+    out = [torch.empty_like(vec) for _ in range(dist.get_world_size(process_group))]
+    dist.all_gather(out, vec, group=process_group)
+    rows = [t.cpu().numpy() for t in out]
+    c, m, v = chan_merge((r[1], r[2:2 + units], r[2 + units:2 + 2 * units]) for r in rows)
+    if m is None:
+        m, v = np.zeros(units, np.float32), np.zeros(units, np.float32)
+    return c, m, v, any(r[0] != 0 for r in rows)
+
+
 def pack(grads: np.ndarray, n_cuts: int) -> np.ndarray:
     """[local gradient of the SUM of squared errors | local cut count | pad] -- the buffer that is all-reduced."""
     buf = np.zeros(grads.size + 4, np.float32)

@@ -289,8 +289,12 @@ def process(model: GCNN, dataloader, fractions: np.ndarray, loss_fn=None, optimi
     return mean_loss, mean_acc
 
 
-def pretrain(model: GCNN, dataloader):
-    """Counterpart of model_trainer.pretrain (model_trainer.py:194-236): fit PreNorm layers one at a time."""
+def pretrain(model: GCNN, dataloader, process_group=None):
+    """Counterpart of model_trainer.pretrain (model_trainer.py:194-236): fit PreNorm layers one at a time.  `dataloader` is
+    iterated once per layer (a list, or any re-iterable).  Data parallel (`process_group` given): every rank passes ITS shard of
+    the pretraining batches (possibly none); after each pass the ranks merge their streaming statistics with one small
+    all-gather (`GCNN.pretrain_sync`), so all ranks freeze identical shift / scale values -- 11 passes over 1/N of the data
+    each instead of every rank redoing all of it."""
     model.pretrain_init()
     i = 0
     while True:
@@ -304,6 +308,7 @@ def pretrain(model: GCNN, dataloader):
                     break
             except torch.OutOfMemoryError:
                 print("WARNING: batch skipped.")
+        model.pretrain_sync(process_group)
         if model.pretrain_next() is None:
             break
         i += 1

@@ -22,6 +22,7 @@ extern "C" {
 #define GCNN_N_PARAMS 62          /* arrays in a checkpoint, model.py:53-56 */
 #define GCNN_E_BADARG (-1)
 #define GCNN_E_WORKSPACE (-2)
+#define GCNN_E_HIP (-3)           /* a HIP call failed inside an entry point whose return value is a count */
 
 /* ---- parameter layout --------------------------------------------------------------------------------------
  * All 62 model variables live in ONE flat fp32 buffer, in the reference's checkpoint order
@@ -31,6 +32,14 @@ int gcnn_abi_version(void);
 int gcnn_param_count(void);                                   /* 62 */
 int gcnn_param_total_floats(void);                            /* size of the flat buffer */
 int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable);
+
+/* ---- per-launch timing (a measuring aid; bench.py's roofline_step) ------------------------------------------------
+ * Between gcnn_profile_begin() and gcnn_profile_end() every kernel launch the library makes is bracketed by two HIP events
+ * on its stream.  gcnn_profile_end waits for those events (the ONE entry point that synchronises), stores up to `capacity`
+ * kernel names (static strings) and durations in milliseconds, launch by launch, and returns the number of launches seen
+ * (possibly > capacity; at most 512 are recorded), or GCNN_E_HIP.  Single-threaded use only. */
+int gcnn_profile_begin(void);
+int gcnn_profile_end(int32_t capacity, const char** names /* host, optional */, float* ms /* host, optional */);
 
 /* ---- sizes ------------------------------------------------------------------------------------------------ */
 typedef struct gcnn_dims {

@@ -199,3 +199,38 @@ def test_checkpoint_and_sample_files_are_unpickled_restrictively(tmp_path):
         pickle.dump({"data": [Evil(), np.zeros(1)]}, f)
     with pytest.raises(pickle.UnpicklingError):
         utils.load_sample(bad)
+
+
+def _prenorm_worker(rank, world, port, tmpdir):
+    """One rank of a data-parallel PreNorm fit on CPU (gloo): streaming statistics over ITS batches, then the rank-ordered merge."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    batches = [rng.standard_normal((int(n), 4)).astype(np.float32) * 3 + 1 for n in (50, 7, 0, 120, 33)]
+    mine = batches[rank::world] if rank == 0 else []          # rank 1 holds nothing at all in the second case below
+    for case, shard in (("split", batches[rank::world]), ("one-sided", mine if rank == 0 else [])):
+        if case == "one-sided" and rank == 0:
+            shard = batches
+        local = parallel.chan_merge((len(b), b.mean(0) if len(b) else np.zeros(4), b.var(0) if len(b) else np.zeros(4)) for b in shard)
+        count, mean, var = local if local[1] is not None else (np.float32(0), np.zeros(4, np.float32), np.zeros(4, np.float32))
+        got = parallel.allgather_prenorm(count, mean, var, len(shard) > 0, dist.group.WORLD, torch.device("cpu"))
+        np.savez(os.path.join(tmpdir, f"pn_{case}_{rank}.npz"), count=got[0], mean=got[1], var=got[2], received=got[3])
+    dist.destroy_process_group()
+
+
+def test_data_parallel_prenorm_fit_matches_single_process(tmp_path):
+    """world_size 2 over gloo: merged statistics == the two-pass population statistics of ALL batches (SURVEY section 4
+    invariant 6), identical on both ranks, also when one rank holds no data."""
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_prenorm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(5)
+    allx = np.concatenate([rng.standard_normal((int(n), 4)).astype(np.float32) * 3 + 1 for n in (50, 7, 0, 120, 33)])
+    for case in ("split", "one-sided"):
+        r0, r1 = (np.load(os.path.join(str(tmp_path), f"pn_{case}_{r}.npz")) for r in range(2))
+        for k in ("count", "mean", "var", "received"):
+            assert np.array_equal(r0[k], r1[k]), (case, k)      # bit-identical on every rank
+        assert float(r0["count"]) == len(allx) and bool(r0["received"])
+        np.testing.assert_allclose(r0["mean"], allx.mean(0), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r0["var"], allx.var(0), rtol=1e-4)
