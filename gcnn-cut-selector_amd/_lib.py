@@ -38,6 +38,11 @@ class AdamArgs(C.Structure):
                 ("beta2", C.c_float), ("eps", C.c_float)]
 
 
+class InferLayout(C.Structure):
+    _fields_ = [("in_bytes", C.c_size_t), ("in_off", C.c_size_t * 8), ("out_bytes", C.c_size_t), ("out_off", C.c_size_t * 3),
+                ("arena_bytes", C.c_size_t), ("dev_off", C.c_size_t * 8)]
+
+
 class CollateJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("unit_kind", C.c_int32), ("width", C.c_int32),
                 ("add_kind", C.c_int32), ("is_ptr", C.c_int32)]
@@ -67,6 +72,8 @@ SIGNATURES = {
     "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gcnn_workspace_floats": (_Z, [_DP]),
     "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _I, _P]),
+    "gcnn_infer_layout_for": (C.c_int, [_DP, C.POINTER(InferLayout)]),
+    "gcnn_infer": (C.c_int, [_DP, _P, _P, _P, _P, _Z, _I, _P]),
     "gcnn_mse_loss": (C.c_int, [_P, _P, _I, _F, _P, _P, _P]),
     "gcnn_forward_loss": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _F, _P]),
     "gcnn_backward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _P, _P, _P, _P, _P]),
@@ -101,7 +108,7 @@ def lib() -> C.CDLL:
 
 def check(rc: int, what: str):
     if rc != 0:
-        kind = {-1: "bad argument", -2: "workspace too small", -3: "HIP call failed"}.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
+        kind = {-1: "bad argument", -2: "workspace too small", -3: "HIP call failed", -4: "unsupported size"}.get(rc, f"hipError_t {rc}" if rc > 0 else f"code {rc}")
         raise GcnnError(f"{what} failed: {kind}")
 
 

@@ -20,6 +20,7 @@
 #include "k_linear.hpp"
 #include "k_misc.hpp"
 #include "k_wgrad.hpp"
+#include "k_infer.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
@@ -562,6 +563,92 @@ extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* con
     return forward_impl(d, p, cons_feats, var_feats, cut_feats, cg, kg, workspace, workspace_floats, scores,
                         save_for_backward != 0, nullptr, 0.f, (hipStream_t)stream);
 }
+// ---- single-state inference: the SCIP cut selector's call (model_evaluator.py:82-111) as ONE entry point --------------------
+static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+extern "C" int gcnn_infer_layout_for(const gcnn_dims* d, gcnn_infer_layout* L) {
+    if (!d || !L || d->n_cons < 0 || d->n_vars < 0 || d->n_cuts < 0 || d->n_cons_edges < 0 || d->n_cut_edges < 0) return GCNN_E_BADARG;
+    if (d->n_vars > IPLAN_MAX_VARS) return GCNN_E_UNSUPPORTED;
+    const size_t C = d->n_cons, V = d->n_vars, K = d->n_cuts, E1 = d->n_cons_edges, E2 = d->n_cut_edges;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al16(bytes); return o; };
+    L->in_off[0] = take(4 * (2 * V + 8 + (C + 1) + (K + 1)));   // zero block: vcount[V] | cursor[V] | flags[8] | l_ptr cons | l_ptr cut
+    L->in_off[1] = take(16 * C);                     // cons_feats [C,4]
+    L->in_off[2] = take(8 * E1);                     // cons_edge_inds [2,E1]
+    L->in_off[3] = take(4 * E1);                     // cons_edge_feats [E1]
+    L->in_off[4] = take(56 * V);                     // var_feats [V,14]
+    L->in_off[5] = take(24 * K);                     // cut_feats [K,6]
+    L->in_off[6] = take(8 * E2);                     // cut_edge_inds [2,E2]
+    L->in_off[7] = take(4 * E2);                     // cut_edge_feats [E2]
+    L->in_bytes = off;
+    L->out_off[0] = 0; L->out_off[1] = al16(4 * K); L->out_off[2] = L->out_off[1] + al16(4 * K);
+    L->out_bytes = L->out_off[2] + 16;               // scores[K] | order[K] | flags[4]
+    // device arena: the uploaded block, the plan, the output block, the forward workspace
+    size_t a = off;
+    auto dev = [&](size_t bytes) { const size_t o = a; a += (bytes + 255) & ~(size_t)255; return o; };
+    L->dev_off[0] = L->in_off[0] + 4 * (2 * V + 8); L->dev_off[1] = L->dev_off[0] + 4 * (C + 1);            // l_ptr cons, l_ptr cut: inside the zero block
+    L->dev_off[2] = dev(4 * (V + 1));                                                                          // v_ptr
+    L->dev_off[3] = dev(4 * E1); L->dev_off[4] = dev(4 * E1); L->dev_off[5] = dev(4 * E1);                    // v_pos, v_oth, v_coef
+    L->dev_off[6] = dev(L->out_bytes);
+    L->dev_off[7] = dev(sizeof(float) * gcnn_workspace_floats(d));
+    L->arena_bytes = a;
+    return 0;
+}
+
+extern "C" int gcnn_infer(const gcnn_dims* d, const float* params, const void* host_in, void* host_out, void* arena,
+                          size_t arena_bytes, int32_t want_order, void* stream) {
+    gcnn_infer_layout L;
+    int rc = gcnn_infer_layout_for(d, &L);
+    if (rc) return rc;
+    if (!params || !host_in || !host_out || !arena || arena_bytes < L.arena_bytes || ((uintptr_t)arena & 255)) return GCNN_E_BADARG;
+    if (want_order && d->n_cuts > 4096) return GCNN_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    char* A = (char*)arena;
+    HIPCHK(hipMemcpyAsync(A, host_in, L.in_bytes, hipMemcpyHostToDevice, st));      // ONE upload: zero block + the seven arrays
+    const int C = d->n_cons, V = d->n_vars, K = d->n_cuts, E1 = d->n_cons_edges, E2 = d->n_cut_edges;
+    int* zero = (int*)(A + L.in_off[0]);
+    IplanArgs ia; memset(&ia, 0, sizeof(ia));
+    ia.s[0] = IplanSet{(int*)(A + L.in_off[2]), E1, C, (int*)(A + L.dev_off[0])};
+    ia.s[1] = IplanSet{(int*)(A + L.in_off[6]), E2, K, (int*)(A + L.dev_off[1])};
+    ia.n_vars = V; ia.vcount = zero; ia.cursor = zero + V; ia.flags = zero + 2 * V;
+    ia.v_ptr = (int*)(A + L.dev_off[2]); ia.v_pos = (int*)(A + L.dev_off[3]); ia.v_oth = (int*)(A + L.dev_off[4]);
+    ia.v_coef = (float*)(A + L.dev_off[5]); ia.cons_coef = (const float*)(A + L.in_off[3]);
+    ia.blocks0 = cdiv(E1 + 1, 256);
+    {
+        ProfScope prof("k_iplan_count", st);
+        hipLaunchKernelGGL(k_iplan_count, dim3(ia.blocks0 + cdiv(E2 + 1, 256)), dim3(256), 0, st, ia);
+        LAUNCHCHK();
+    }
+    {
+        static PerDeviceOnce attr;
+        if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_iplan_place, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (IPLAN_MAX_VARS + 1)));
+        ProfScope prof("k_iplan_place", st);
+        hipLaunchKernelGGL(k_iplan_place, dim3(std::max(1, std::min(cdiv(E1, 1024), 64))), dim3(1024), 4 * (size_t)(V + 1), st, ia);
+        LAUNCHCHK();
+    }
+    if (V > 0) {
+        ProfScope prof("k_iplan_order", st);
+        hipLaunchKernelGGL(k_iplan_order, dim3(cdiv(V, 16)), dim3(256), 0, st, ia);
+        LAUNCHCHK();
+    }
+    gcnn_graph cg, kg; memset(&cg, 0, sizeof(cg)); memset(&kg, 0, sizeof(kg));
+    cg.l_ptr = ia.s[0].l_ptr; cg.l_oth = ia.s[0].inds + E1; cg.l_coef = ia.cons_coef;       // by-left order = the input lists
+    cg.v_ptr = ia.v_ptr; cg.v_oth = ia.v_oth; cg.v_coef = ia.v_coef;
+    kg.l_ptr = ia.s[1].l_ptr; kg.l_oth = ia.s[1].inds + E2; kg.l_coef = (const float*)(A + L.in_off[7]);
+    kg.v_ptr = ia.v_ptr;   // never read: conv v->k gathers by cut only and nothing is differentiated
+    float* out = (float*)(A + L.dev_off[6]);
+    rc = gcnn_forward(d, params, (const float*)(A + L.in_off[1]), (const float*)(A + L.in_off[4]), (const float*)(A + L.in_off[5]),
+                      &cg, &kg, (float*)(A + L.dev_off[7]), gcnn_workspace_floats(d), out, 0, stream);
+    if (rc) return rc;
+    if (want_order && K > 0) {
+        ProfScope prof("k_rank_scores", st);
+        hipLaunchKernelGGL(k_rank_scores, dim3(1), dim3(256), 0, st, out, K, (int*)((char*)out + L.out_off[1]));
+        LAUNCHCHK();
+    }
+    HIPCHK(hipMemcpyAsync((char*)out + L.out_off[2], ia.flags, 16, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(host_out, out, L.out_bytes, hipMemcpyDeviceToHost, st));  // ONE download: scores | order | flags
+    return 0;
+}
+
 extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                       const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                       size_t workspace_floats, float* scores, const float* targets, float loss_scale, void* stream) {

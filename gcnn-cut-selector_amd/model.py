@@ -69,6 +69,101 @@ class ScoreTensor(torch.Tensor):
         return torch.Tensor.numpy(self.detach().cpu().as_subclass(torch.Tensor), *args, **kwargs)
 
 
+class ScoreArray(np.ndarray):
+    """Host-side scores of the single-state inference path: an ndarray that also answers `.numpy()` (the reference's call sites do
+    `get_improvements(state, False).numpy()`, model_evaluator.py:103).  `rankings` (optional): indices in descending score
+    order, equal scores in index order -- `sorted(range(n), key=lambda x: quality[x], reverse=True)` of model_evaluator.py:110."""
+    rankings = None
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+class _UseGeneralPath(Exception):
+    """The specialised single-state path declined (unsorted edge list, very long segment, too many variables)."""
+
+
+class _InferenceSession:
+    """Host side of gcnn_infer (include/gcnn_hip.h): persistent pinned staging buffers and a device arena, one C call per state."""
+
+    def __init__(self, model):
+        self.model = model
+        self.pin_in = self.pin_out = self.arena = None
+        self.in_np = self.out_np = None
+        self.layouts = {}
+
+    def _layout(self, key):
+        lay = self.layouts.get(key)
+        if lay is None:
+            dims, lay = _lib.Dims(*key), _lib.InferLayout()
+            rc = _lib.lib().gcnn_infer_layout_for(C.byref(dims), C.byref(lay))
+            if rc == -4:
+                lay = False
+            else:
+                _lib.check(rc, "gcnn_infer_layout_for")
+                lay = (dims, lay, list(lay.in_off), list(lay.out_off))
+            if len(self.layouts) > 256:
+                self.layouts.clear()
+            self.layouts[key] = lay
+        return lay
+
+    def run(self, inputs, want_order):
+        c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts = inputs
+        c, v, k = np.asarray(c), np.asarray(v), np.asarray(k)
+        cei, kei, cef, kef = np.asarray(cei), np.asarray(kei), np.asarray(cef), np.asarray(kef)
+        for name, t, f in (("cons_feats", c, 4), ("var_feats", v, 14), ("cut_feats", k, 6)):
+            if t.ndim != 2 or t.shape[1] != f:
+                raise ValueError(f"{name} must have shape [N,{f}], got {tuple(t.shape)}")
+        for name, total, t in (("n_cons", n_cons, c), ("n_vars", n_vars, v), ("n_cuts", n_cuts, k)):
+            if int(total) != t.shape[0]:
+                raise ValueError(f"{name}={int(total)} does not match the {t.shape[0]} feature rows")
+        for name, ei, ef in (("cons_edge_inds", cei, cef), ("cut_edge_inds", kei, kef)):
+            if ei.ndim != 2 or ei.shape[0] != 2 or ei.dtype.kind not in "iu":
+                raise ValueError(f"{name} must be an integer array of shape [2,E], got {ei.dtype} {tuple(ei.shape)}")
+            if ef.size != ei.shape[1]:
+                raise ValueError("edge features must hold one value per edge")
+        key = (c.shape[0], v.shape[0], k.shape[0], cei.shape[1], kei.shape[1])
+        lay = self._layout(key)
+        if lay is False or (want_order and key[2] > 4096):
+            raise _UseGeneralPath()
+        dims, L, in_off, out_off = lay
+        dev = self.model.device
+        if self.pin_in is None or self.pin_in.numel() < L.in_bytes:
+            self.pin_in = torch.empty(max(2 * L.in_bytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            self.in_np = self.pin_in.numpy()
+        if self.pin_out is None or self.pin_out.numel() < L.out_bytes:
+            self.pin_out = torch.empty(max(2 * L.out_bytes, 1 << 16), dtype=torch.uint8).pin_memory()
+            self.out_np = self.pin_out.numpy()
+        if self.arena is None or self.arena.numel() < L.arena_bytes:
+            self.arena = None
+            self.arena = torch.empty(max(2 * L.arena_bytes, 1 << 24), dtype=torch.uint8, device=dev)
+        buf = self.in_np
+        buf[in_off[0]:in_off[1]] = 0      # the plan's counters and flags travel zeroed inside the upload
+        for off, a, dt in ((in_off[1], c, np.float32), (in_off[2], cei, np.int32), (in_off[3], cef, np.float32),
+                           (in_off[4], v, np.float32), (in_off[5], k, np.float32), (in_off[6], kei, np.int32),
+                           (in_off[7], kef, np.float32)):
+            if a.size:
+                np.copyto(buf[off:off + 4 * a.size].view(dt).reshape(a.shape), a, casting="unsafe")
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev)
+            _lib.check(_lib.lib().gcnn_infer(C.byref(dims), C.c_void_p(self.model._flat.data_ptr()),
+                                            C.c_void_p(self.pin_in.data_ptr()), C.c_void_p(self.pin_out.data_ptr()),
+                                            C.c_void_p(self.arena.data_ptr()), self.arena.numel(), int(want_order),
+                                            C.c_void_p(stream.cuda_stream)), "gcnn_infer")
+            stream.synchronize()
+        out = self.out_np
+        flags = out[out_off[2]:out_off[2] + 16].view(np.int32)
+        if flags[0]:
+            raise ValueError("edge index out of range (left ids must be in [0,n_left), variable ids in [0,n_vars))")
+        if flags[1] or flags[2] or flags[3]:
+            raise _UseGeneralPath()
+        n = key[2]
+        scores = out[out_off[0]:out_off[0] + 4 * n].view(np.float32).copy().view(ScoreArray)
+        if want_order:
+            scores.rankings = out[out_off[1]:out_off[1] + 4 * n].view(np.int32).copy()
+        return scores
+
+
 class Batch:
     """A stacked mini-batch resident on the GPU: features + both CSR orders of both edge sets (GCNN.prepare)."""
 
@@ -150,6 +245,7 @@ class GCNN:
                                  ("float32", (None, 14)), ("float32", (None, 6)), ("int32", (2, None)),
                                  ("float32", (None, 1)), ("int32", ()), ("int32", ()), ("int32", ())), ("bool", ())]
         self._ws_pool = []
+        self._session = None      # single-state inference (gcnn_infer): pinned staging + device arena, created on first use
         self._pin = None          # pinned host staging buffer for prepare()
         self._pin_event = None
         self._prenorm_state = None
@@ -439,10 +535,30 @@ class GCNN:
                 return i, scale_name.rsplit("/", 1)[0]
         return None
 
+    def score_state(self, inputs, rank=False):
+        """Scores of ONE sampled state given as host arrays (the SCIP plugins' call, model_evaluator.py:84-111), through the
+        single-call path gcnn_infer: one upload, a three-launch graph plan, the inference forward pass, one download.
+        Returns a `ScoreArray` (ndarray with `.numpy()`); with `rank=True` its `.rankings` holds the cut indices in descending
+        score order (ties in index order).  States the specialised plan declines (edge lists not sorted by row, more than
+        32,768 variables, ...) run through `prepare` + the general forward pass instead; results are identical."""
+        if self._session is None:
+            self._session = _InferenceSession(self)
+        try:
+            return self._session.run(inputs, rank)
+        except _UseGeneralPath:
+            with torch.no_grad():
+                scores = self.call(inputs, False).numpy().view(ScoreArray)
+            if rank:
+                scores.rankings = np.argsort(-np.asarray(scores), kind="stable").astype(np.int32)
+            return scores
+
     def get_concrete_function(self):
         """Counterpart of `tf.function(model.call).get_concrete_function()` (model_evaluator.py:310-311): an inference
-        callable `(state10, training) -> scores` with `.numpy()`."""
-        def get_improvements(state, training=False):
-            with torch.no_grad():
-                return self.call(state, training)
+        callable `(state10, training) -> scores` with `.numpy()`.  Host arrays (what `get_state` produces) take the
+        single-call path `score_state`; device tensors / prepared batches the general forward pass."""
+        def get_improvements(state, training=False, rank=False):
+            if isinstance(state, Batch) or any(isinstance(x, torch.Tensor) for x in state[:7]):
+                with torch.no_grad():
+                    return self.call(state, training)
+            return self.score_state(state, rank)
         return get_improvements

@@ -22,6 +22,7 @@ extern "C" {
 #define GCNN_N_PARAMS 62          /* arrays in a checkpoint, model.py:53-56 */
 #define GCNN_E_BADARG (-1)
 #define GCNN_E_WORKSPACE (-2)
+#define GCNN_E_UNSUPPORTED (-4)   /* sizes outside what a specialised entry point handles: use the general path */
 #define GCNN_E_HIP (-3)           /* a HIP call failed inside an entry point whose return value is a count */
 
 /* ---- parameter layout --------------------------------------------------------------------------------------
@@ -149,6 +150,31 @@ int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_f
  * scale = 1/n gives Keras' mean; data-parallel callers pass 1/global_cut_count.  loss_out / d_scores may be NULL. */
 int gcnn_mse_loss(const float* scores, const float* targets, int32_t n, float scale, float* loss_out,
                   float* d_scores, void* stream);
+
+/* ---- single-state inference: what the SCIP cut selector does per separation round, model_evaluator.py:82-111 --------
+ * get_state -> ten tf.convert_to_tensor -> get_improvements(state, False).numpy() -> sorted(range(n), key=quality, reverse=True)
+ * as ONE call on ONE stream: one host->device copy of the packed inputs, a three-launch graph plan specialised to a single
+ * (row, col)-sorted state (utils.py:102-104), the inference forward pass, optionally the descending stable ranking of the
+ * scores, one device->host copy.  Nothing is synchronised: after the call returns, wait on `stream`, then read host_out.
+ *
+ * host_in  (pinned): gcnn_infer_layout.in_bytes bytes; in_off[0] .. in_off[1] = a block the CALLER keeps zero (counters, flags
+ *          and offset arrays of the plan ride in the upload instead of a memset), in_off[1..7] = cons_feats [C,4] f32, cons_edge_inds
+ *          [2,E1] i32, cons_edge_feats [E1] f32, var_feats [V,14] f32, cut_feats [K,6] f32, cut_edge_inds [2,E2] i32,
+ *          cut_edge_feats [E2] f32 (the reference's input tuple, model.py:263-275).
+ * host_out (pinned): out_bytes bytes; out_off[0] scores [K] f32 (model.py:300), out_off[1] order [K] i32 (only when
+ *          want_order: order[0] = index of the best cut, equal scores in index order), out_off[2] four int32 flags:
+ *          [0] an edge index out of range, [1] / [2] constraint / cut edges not sorted by row, [3] a variable with more than
+ *          2,048 edges.  Any flag set => the scores are NOT valid: raise on [0], otherwise use gcnn_graph_build + gcnn_forward.
+ * arena    (device, 256-byte aligned, arena_bytes): inputs, plan, outputs and the forward workspace; caller-owned, reusable.
+ * Returns GCNN_E_UNSUPPORTED for more than 32,768 variables (or want_order with more than 4,096 cuts). */
+typedef struct gcnn_infer_layout {
+    size_t in_bytes, in_off[8];
+    size_t out_bytes, out_off[3];
+    size_t arena_bytes, dev_off[8];   /* dev_off: internal carving of the arena behind the uploaded block */
+} gcnn_infer_layout;
+int gcnn_infer_layout_for(const gcnn_dims* dims, gcnn_infer_layout* layout /* host */);
+int gcnn_infer(const gcnn_dims* dims, const float* params, const void* host_in, void* host_out, void* arena,
+               size_t arena_bytes, int32_t want_order, void* stream);
 
 /* Keras-form Adam step (see gcnn_adam_step) to run right behind a backward pass. */
 typedef struct gcnn_adam_args {

@@ -1,18 +1,27 @@
-import sys, time; sys.path.insert(0,'.')
+"""Single-state inference latency through GCNN.get_concrete_function() -- the SCIP plugin's call shape
+(model_evaluator.py:82-111).  End to end = host arrays in, scores (and ranking) back on the host."""
+import sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
-from gcnn_cut_selector_amd import synthetic, utils
+from gcnn_cut_selector_amd import _lib, synthetic, utils
 from gcnn_cut_selector_amd.model import GCNN
-dev=torch.device('cuda',0)
-m=GCNN(device=dev, seed=0)
-f=m.get_concrete_function()
-for prob in ["setcov","combauc","capfac","indset"]:
-    state,_=synthetic.make_sample(prob, 7)
-    inp=utils.state_to_inputs(state)
-    for _ in range(5): f(inp, False).numpy()
-    ts=[]; tp=[]; tf=[]
-    for _ in range(30):
-        t0=time.perf_counter(); b=m.prepare(inp); torch.cuda.synchronize(); t1=time.perf_counter()
-        q=f(b, False); q=q.numpy(); t2=time.perf_counter()
-        tp.append(t1-t0); tf.append(t2-t1)
-        t0=time.perf_counter(); q=f(inp, False).numpy(); ts.append(time.perf_counter()-t0)
-    print(f"{prob:8s} cuts={inp[9]:4d} E={inp[1].shape[1]+inp[5].shape[1]:6d} end-to-end {np.median(ts)*1e3:.3f} ms  (prepare {np.median(tp)*1e3:.3f} ms, forward+D2H {np.median(tf)*1e3:.3f} ms)")
+dev = torch.device('cuda', 0)
+m = GCNN(device=dev, seed=0)
+f = m.get_concrete_function()
+med = lambda xs: float(np.median(xs)) * 1e3
+for prob in ["setcov", "combauc", "capfac", "indset"]:
+    state, _ = synthetic.make_sample(prob, 7)
+    inp = utils.state_to_inputs(state)
+    for _ in range(10): f(inp, False).numpy()
+    t_fast, t_rank, t_gen = [], [], []
+    for _ in range(50):
+        t0 = time.perf_counter(); q = f(inp, False).numpy(); t_fast.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); q = f(inp, False, rank=True); q.numpy(); t_rank.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        with torch.no_grad(): g = m(inp, False).numpy()
+        t_gen.append(time.perf_counter() - t0)
+    with _lib.launch_profile() as prof:
+        f(inp, False, rank=True)
+    dev_us = sum(ms for _, ms in prof.launches) * 1e3
+    print(f"{prob:8s} cuts={inp[9]:4d} E={inp[1].shape[1] + inp[5].shape[1]:6d}  gcnn_infer end-to-end {med(t_fast):.3f} ms  (+ranking {med(t_rank):.3f} ms)  "
+          f"general path (prepare + forward) {med(t_gen):.3f} ms   kernels: {len(prof.launches)} launches, {dev_us:.0f} us under event brackets")
+    print("          " + "  ".join(f"{n}:{ms * 1e3:.1f}" for n, ms in prof.launches))
