@@ -93,30 +93,59 @@ static inline int edge_slots(int n_own, int n_edges) {
     const double avg = (double)n_edges / (double)std::max(n_own, 1);
     return avg >= 40.0 ? 4 : (avg >= 12.0 ? 2 : 1);
 }
+// Segments longer than edge_long_threshold(slots) are left to a second launch that gives each a whole wave (k_edge.hpp).
+// max_deg = longest segment of the list if the caller knows it (gcnn_graph.*_max_deg), 0 = unknown: then the finder always runs.
+static inline bool edge_needs_long_pass(int slots, int max_deg) {
+    return slots < 4 && (max_deg <= 0 || max_deg > edge_long_threshold(slots));
+}
+static inline int edge_long_grid(int n_own) { return std::max(1, std::min(cdiv(n_own, 4), MAX_GRID)); }
 // forward (owner = receiver); `count` also emits the N rows (active edges per receiver and channel) for the backward pass
-static int launch_edge_fwd(const EdgeArgs& a, int n_edges, bool count, hipStream_t st) {
+static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool count, hipStream_t st) {
     if (a.n_own <= 0) return 0;
     if (count && !a.cnt_rows) return GCNN_E_BADARG;
-    const int slots = edge_slots(a.n_own, n_edges);
+    // inference on a small graph (one sampled state): latency, not lane efficiency, decides -- a whole wave per segment needs no
+    // long-segment launch and finishes a hub row in a quarter of the gather rounds
+    const int slots = (!count && a.n_own <= 16384) ? 4 : edge_slots(a.n_own, n_edges);
+    if (!count && a.n_own <= 1024 && n_edges >= 48ll * a.n_own) {   // a few long segments: a block each (k_edge_fwd_block)
+        ProfScope prof("k_edge_fwd_block", st);
+        hipLaunchKernelGGL(k_edge_fwd_block, dim3(a.n_own), dim3(256), 0, st, a);
+        LAUNCHCHK();
+        return 0;
+    }
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
-    ProfScope prof(count ? "k_edge_fwd<count>" : "k_edge_fwd", st);
+    {
+        ProfScope prof(count ? "k_edge_fwd<count>" : "k_edge_fwd", st);
 #define EDGE_LAUNCH(S, V) hipLaunchKernelGGL((k_edge_fwd<S, V>), dim3(grid), dim3(256), 0, st, a)
-    if (count) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
-    else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
+        if (count) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
+        else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
 #undef EDGE_LAUNCH
-    LAUNCHCHK();
+        LAUNCHCHK();
+    }
+    if (edge_needs_long_pass(slots, max_deg)) {
+        ProfScope prof(count ? "k_edge_fwd_long<count>" : "k_edge_fwd_long", st);
+        if (count) hipLaunchKernelGGL(k_edge_fwd_long<true>, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
+        else hipLaunchKernelGGL(k_edge_fwd_long<false>, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
+        LAUNCHCHK();
+    }
     return 0;
 }
 // backward, sender-ordered (owner = sender)
-static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, hipStream_t st) {
+static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, int max_deg, hipStream_t st) {
     if (a.n_own <= 0) return 0;
     const int slots = edge_slots(a.n_own, n_edges);
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
-    ProfScope prof("k_edge_bwd_send", st);
-    if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
-    else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
-    LAUNCHCHK();
+    {
+        ProfScope prof("k_edge_bwd_send", st);
+        if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
+        else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
+        LAUNCHCHK();
+    }
+    if (edge_needs_long_pass(slots, max_deg)) {
+        ProfScope prof("k_edge_bwd_send_long", st);
+        hipLaunchKernelGGL(k_edge_bwd_send_long, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
+        LAUNCHCHK();
+    }
     return 0;
 }
 
@@ -178,7 +207,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 7; }
+int gcnn_abi_version(void) { return 8; }
 
 int gcnn_profile_begin(void) { g_prof.n = 0; g_prof.on = true; return 0; }
 int gcnn_profile_end(int32_t capacity, const char** names, float* ms) {
@@ -347,14 +376,14 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
 }
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
-                       const float* e_scale, const float* s1, float* s_out, float* n_rows, void* stream) {
+                       const float* e_scale, const float* s1, float* s_out, float* n_rows, int32_t max_degree, void* stream) {
     if (n_recv < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_recv > 0 && (!seg_ptr || !p_recv || !w_edge || !e_shift || !e_scale || !s1 || !s_out)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_oth)) return GCNN_E_BADARG;
     EdgeArgs e; memset(&e, 0, sizeof(e));
     e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_own = p_recv; e.p_oth = p_oth; e.w_edge = w_edge;
     e.e_shift = e_shift; e.e_scale = e_scale; e.s1 = s1; e.out = s_out; e.cnt_rows = n_rows; e.n_own = n_recv;
-    return launch_edge_fwd(e, n_edges, n_rows != nullptr, (hipStream_t)stream);
+    return launch_edge_fwd(e, n_edges, max_degree, n_rows != nullptr, (hipStream_t)stream);
 }
 int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
                             void* stream) {
@@ -368,14 +397,14 @@ int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* 
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send, int32_t n_edges,
                             const float* p_send, const float* p_recv, const float* w_edge, const float* e_shift,
                             const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
-                            void* stream) {
+                            int32_t max_degree, void* stream) {
     if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
     if (n_send > 0 && (!seg_ptr || !p_send || !w_edge || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_recv || !d_s)) return GCNN_E_BADARG;
     EdgeArgs e; memset(&e, 0, sizeof(e));
     e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_own = p_send; e.p_oth = p_recv; e.w_edge = w_edge; e.s1 = s1;
     e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_own = n_send;
-    return launch_edge_bwd_send(e, n_edges, (hipStream_t)stream);
+    return launch_edge_bwd_send(e, n_edges, max_degree, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -483,7 +512,7 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
     int rc;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
     e.out = c.S; e.cnt_rows = c.N;
-    if ((rc = launch_edge_fwd(e, c.ne, save, st))) return rc;
+    if ((rc = launch_edge_fwd(e, c.ne, c.recv_left ? c.g->l_max_deg : c.g->v_max_deg, save, st))) return rc;
     ConvFArgs a; memset(&a, 0, sizeof(a));
     a.n = c.recv_left ? c.nl : c.nv;
     a.s = c.S; a.seg_ptr = e.seg_ptr; a.wf = p + poff(c.pbase + C_WF); a.bf = p + poff(c.pbase + C_BF); a.a_out = save ? c.A : nullptr;
@@ -710,7 +739,7 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     // (the ReLU pattern is recomputed), which also yields Q, the per-sender share of d w_edge
     EdgeArgs e = conv_edge_args(p, c, !c.recv_left);
     e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q;
-    if ((rc = launch_edge_bwd_send(e, c.ne, st))) return rc;
+    if ((rc = launch_edge_bwd_send(e, c.ne, c.recv_left ? c.g->v_max_deg : c.g->l_max_deg, st))) return rc;
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
     float* gwe = grads + poff(c.pbase + C_WE);
     add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);

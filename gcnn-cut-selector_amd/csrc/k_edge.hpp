@@ -39,61 +39,95 @@ __device__ __forceinline__ float4 slot_reduce(float4 v) {
     return v;
 }
 
+// Long segments.  With fewer than 64 lanes per segment (SLOTS < 4: graphs of low mean degree) a segment of hundreds of edges
+// would keep one 16- or 32-lane group busy for dozens of dependent gather rounds while the rest of the chip has finished:
+// capfac has 201 rows of 100 edges among 10,000 rows of 2 (instance_generator.py:569-647), indset Barabasi-Albert hubs
+// (:44-143).  The main kernels therefore SKIP segments longer than edge_long_threshold(SLOTS); a second launch (k_edge_*_long)
+// finds them -- every wave looks at rows w, w+W, w+2W, ... so that neighbouring hub rows land in different waves -- and gives
+// each a whole wave.  The host launches it only when the graph has such a segment (gcnn_graph.*_max_deg; 0 = unknown).
+__host__ __device__ constexpr int edge_long_threshold(int slots) { return slots >= 4 ? 0x7fffffff : 32 * slots; }
+
+template <int SLOTS>
+struct EdgeLane {   // lane geometry of a G = 16*SLOTS lane group
+    int gl, gbase, slot, ch;
+    __device__ __forceinline__ EdgeLane() {
+        const int lane = threadIdx.x & 63;
+        gl = lane % (16 * SLOTS); gbase = lane - gl; slot = gl >> 4; ch = (gl & 15) * 4;
+    }
+};
+
 // Forward edge pass.  relu(s1*J) = s1*max(J,0) for s1 >= 0 and s1*min(J,0) for s1 < 0, so the scale is applied once per
 // receiver.  J_e = (c_e*w + P_oth[oth_e]) + P_own[r].  COUNT also emits N (training; inference skips it).
+// One segment [beg, end) of receiver r by one lane group (every lane of the group must call).
+struct EdgeSum { float4 acc, cnt; };   // per lane group, after the slot reduction: sum_e max/min(J_e, 0) and the active-edge counts
+template <int SLOTS, bool COUNT, bool NEG>
+__device__ __forceinline__ EdgeSum edge_fwd_partial(const EdgeArgs& a, const EdgeLane<SLOTS>& L, const float4 w, const float esh,
+                                                    const float esc, const int r, const int beg, const int end) {
+    constexpr int G = 16 * SLOTS;
+    const int gl = L.gl, gbase = L.gbase, slot = L.slot, ch = L.ch;
+    const float4 pown = *(const float4*)(a.p_own + (size_t)r * EMB + ch);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    for (int base = beg; base < end; base += G) {
+        const int e = base + gl;
+        int o = 0; float c = 0.f;
+        if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
+        const int cnt = min(G, end - base);
+        for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
+            int oi[4]; float ci[4]; bool ok[4]; float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * SLOTS + slot;
+                ok[u] = i < cnt;
+                const int src = gbase + (ok[u] ? i : 0);
+                oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ok[u]) {
+                    float h0 = fmaf(ci[u], w.x, p[u].x) + pown.x, h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
+                    float h2 = fmaf(ci[u], w.z, p[u].z) + pown.z, h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
+                    h0 = NEG ? fminf(h0, 0.f) : fmaxf(h0, 0.f); h1 = NEG ? fminf(h1, 0.f) : fmaxf(h1, 0.f);
+                    h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
+                    acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
+                    if (COUNT) {   // after the clamp "active" is "non-zero" (h = +-0 when clamped)
+                        n0 += h0 != 0.f; n1 += h1 != 0.f; n2 += h2 != 0.f; n3 += h3 != 0.f;
+                    }
+                }
+            }
+        }
+    }
+    EdgeSum out;
+    out.acc = slot_reduce<SLOTS>(acc);
+    out.cnt = COUNT ? slot_reduce<SLOTS>(make_float4((float)n0, (float)n1, (float)n2, (float)n3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return out;
+}
+template <int SLOTS, bool COUNT, bool NEG>
+__device__ __forceinline__ void edge_fwd_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
+                                                 const float esh, const float esc, const int r, const int beg, const int end) {
+    const EdgeSum t = edge_fwd_partial<SLOTS, COUNT, NEG>(a, L, w, esh, esc, r, beg, end);
+    if (L.slot == 0) {
+        *(float4*)(a.out + (size_t)r * EMB + L.ch) = make_float4(s1 * t.acc.x, s1 * t.acc.y, s1 * t.acc.z, s1 * t.acc.w);
+        if (COUNT) *(float4*)(a.cnt_rows + (size_t)r * EMB + L.ch) = t.cnt;
+    }
+}
+
 template <int SLOTS, bool COUNT, bool NEG>
 __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
-    const float4 w = *(const float4*)(a.w_edge + ch);
+    const EdgeLane<SLOTS> L;
+    const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
     const int nwork = (a.n_own + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
         const int r = item * RPW + lane / G;
         if (r < a.n_own) {
             const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
-            const float4 pown = *(const float4*)(a.p_own + (size_t)r * EMB + ch);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-            for (int base = beg; base < end; base += G) {
-                const int e = base + gl;
-                int o = 0; float c = 0.f;
-                if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
-                const int cnt = min(G, end - base);
-                for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 p[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u * SLOTS + slot;
-                        ok[u] = i < cnt;
-                        const int src = gbase + (ok[u] ? i : 0);
-                        oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (ok[u]) {
-                            float h0 = fmaf(ci[u], w.x, p[u].x) + pown.x, h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
-                            float h2 = fmaf(ci[u], w.z, p[u].z) + pown.z, h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
-                            h0 = NEG ? fminf(h0, 0.f) : fmaxf(h0, 0.f); h1 = NEG ? fminf(h1, 0.f) : fmaxf(h1, 0.f);
-                            h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
-                            acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
-                            if (COUNT) {   // after the clamp "active" is "non-zero" (h = +-0 when clamped)
-                                n0 += h0 != 0.f; n1 += h1 != 0.f; n2 += h2 != 0.f; n3 += h3 != 0.f;
-                            }
-                        }
-                    }
-                }
-            }
-            acc = slot_reduce<SLOTS>(acc);
-            if (slot == 0) *(float4*)(a.out + (size_t)r * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
-            if (COUNT) {
-                const float4 nacc = slot_reduce<SLOTS>(make_float4((float)n0, (float)n1, (float)n2, (float)n3));
-                if (slot == 0) *(float4*)(a.cnt_rows + (size_t)r * EMB + ch) = nacc;
-            }
+            if (end - beg <= edge_long_threshold(SLOTS)) edge_fwd_segment<SLOTS, COUNT, NEG>(a, s1, L, w, esh, esc, r, beg, end);
         }
     }
 }
@@ -102,6 +136,61 @@ template <int SLOTS, bool COUNT>
 __global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
     const float s1 = *a.s1;
     if (s1 < 0.f) edge_fwd_impl<SLOTS, COUNT, true>(a, s1); else edge_fwd_impl<SLOTS, COUNT, false>(a, s1);
+}
+
+// Inference on ONE sampled state with long segments (the cut rows of conv v->k: a few dozen cuts of 10-200 nonzeros each): a
+// wave per segment would walk a dozen dependent gather rounds with most of the chip idle.  Here a 4-wave block serves one
+// segment, each wave a contiguous quarter, and the four partial sums are added in a fixed order.
+__global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) {
+    __shared__ float4 red[4][16];
+    const float s1 = *a.s1;
+    const EdgeLane<4> L;
+    const float4 w = *(const float4*)(a.w_edge + L.ch);
+    const float esh = *a.e_shift, esc = *a.e_scale;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = blockIdx.x; r < a.n_own; r += gridDim.x) {
+        const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
+        const int chunk = ((end - beg + 3) / 4 + 15) & ~15;
+        const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
+        const EdgeSum t = s1 < 0.f ? edge_fwd_partial<4, false, true>(a, L, w, esh, esc, r, b, e)
+                                   : edge_fwd_partial<4, false, false>(a, L, w, esh, esc, r, b, e);
+        if (lane < 16) red[wv][lane] = t.acc;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const float4 p0 = red[0][lane], p1 = red[1][lane], p2 = red[2][lane], p3 = red[3][lane];
+            *(float4*)(a.out + (size_t)r * EMB + L.ch) = make_float4(s1 * ((p0.x + p1.x) + (p2.x + p3.x)), s1 * ((p0.y + p1.y) + (p2.y + p3.y)),
+                                                                  s1 * ((p0.z + p1.z) + (p2.z + p3.z)), s1 * ((p0.w + p1.w) + (p2.w + p3.w)));
+        }
+        __syncthreads();
+    }
+}
+
+// The rows the main kernel left out (longer than `thresh`), one wave each.  `body(r, beg, end)` is called wave-uniformly.
+template <class Body>
+__device__ __forceinline__ void edge_long_rows(const int* __restrict__ seg_ptr, int n_own, int thresh, Body body) {
+    const int lane = threadIdx.x & 63;
+    const int W = gridDim.x * 4, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int q0 = 0; (long long)q0 * W + w < n_own; q0 += 64) {   // wave w owns rows w, w + W, w + 2W, ...
+        const long long rr = (long long)(q0 + lane) * W + w;
+        const int r = rr < n_own ? (int)rr : -1;
+        int beg = 0, end = 0;
+        if (r >= 0) { beg = seg_ptr[r]; end = seg_ptr[r + 1]; }
+        unsigned long long m = __ballot(end - beg > thresh);
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            body(__shfl(r, b), __shfl(beg, b), __shfl(end, b));
+        }
+    }
+}
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_edge_fwd_long(EdgeArgs a, int thresh) {
+    const float s1 = *a.s1;
+    const EdgeLane<4> L;
+    const float4 w = *(const float4*)(a.w_edge + L.ch);
+    const float esh = *a.e_shift, esc = *a.e_scale;
+    if (s1 < 0.f) edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int r, int beg, int end) { edge_fwd_segment<4, COUNT, true>(a, s1, L, w, esh, esc, r, beg, end); });
+    else edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int r, int beg, int end) { edge_fwd_segment<4, COUNT, false>(a, s1, L, w, esh, esc, r, beg, end); });
 }
 
 // Backward, receiver-ordered half, element-wise: dP_recv[r] = s1*dS[r]*N[r].  (The model fuses this into the epilogue of
@@ -121,56 +210,63 @@ __global__ __launch_bounds__(256) void k_edge_bwd_recv(const float* __restrict__
 //   dP_send[u] = s1 * sum_{e in seg(u)} t_e          Q[u] = s1 * sum_{e in seg(u)} c_e * t_e   (share of d w_edge)
 // two 256-B row gathers per edge (dS and P_recv, same row index), nothing else.
 template <int SLOTS, bool NEG>
+__device__ __forceinline__ void edge_bwd_send_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
+                                                      const float esh, const float esc, const int u, const int beg, const int end) {
+    constexpr int G = 16 * SLOTS;
+    const int gl = L.gl, gbase = L.gbase, slot = L.slot, ch = L.ch;
+    const float4 psend = *(const float4*)(a.p_own + (size_t)u * EMB + ch);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
+    for (int base = beg; base < end; base += G) {
+        const int e = base + gl;
+        int o = 0; float c = 0.f;
+        if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
+        const int cnt = min(G, end - base);
+        for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
+            int oi[4]; float ci[4]; bool ok[4]; float4 d[4], q[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = i0 + v * SLOTS + slot;
+                ok[v] = i < cnt;
+                const int src = gbase + (ok[v] ? i : 0);
+                oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (ok[v]) {
+                    d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
+                    q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
+                }
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (ok[v]) {
+                    const float j0 = fmaf(ci[v], w.x, psend.x) + q[v].x, j1 = fmaf(ci[v], w.y, psend.y) + q[v].y;
+                    const float j2 = fmaf(ci[v], w.z, psend.z) + q[v].z, j3 = fmaf(ci[v], w.w, psend.w) + q[v].w;
+                    const float t0 = (NEG ? j0 < 0.f : j0 > 0.f) ? d[v].x : 0.f, t1 = (NEG ? j1 < 0.f : j1 > 0.f) ? d[v].y : 0.f;
+                    const float t2 = (NEG ? j2 < 0.f : j2 > 0.f) ? d[v].z : 0.f, t3 = (NEG ? j3 < 0.f : j3 > 0.f) ? d[v].w : 0.f;
+                    acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
+                    dw.x = fmaf(ci[v], t0, dw.x); dw.y = fmaf(ci[v], t1, dw.y); dw.z = fmaf(ci[v], t2, dw.z); dw.w = fmaf(ci[v], t3, dw.w);
+                }
+        }
+    }
+    acc = slot_reduce<SLOTS>(acc); dw = slot_reduce<SLOTS>(dw);
+    if (slot == 0) {
+        *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
+        *(float4*)(a.dw_rows + (size_t)u * EMB + ch) = make_float4(s1 * dw.x, s1 * dw.y, s1 * dw.z, s1 * dw.w);
+    }
+}
+template <int SLOTS, bool NEG>
 __device__ __forceinline__ void edge_bwd_send_impl(const EdgeArgs& a, const float s1) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gl = lane % G, gbase = lane - gl, slot = gl >> 4, cl = gl & 15, ch = cl * 4;
+    const EdgeLane<SLOTS> L;
     const float esh = *a.e_shift, esc = *a.e_scale;
-    const float4 w = *(const float4*)(a.w_edge + ch);
+    const float4 w = *(const float4*)(a.w_edge + L.ch);
     const int nwork = (a.n_own + RPW - 1) / RPW;
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
         const int u = item * RPW + lane / G;
         if (u < a.n_own) {
             const int beg = a.seg_ptr[u], end = a.seg_ptr[u + 1];
-            const float4 psend = *(const float4*)(a.p_own + (size_t)u * EMB + ch);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
-            for (int base = beg; base < end; base += G) {
-                const int e = base + gl;
-                int o = 0; float c = 0.f;
-                if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
-                const int cnt = min(G, end - base);
-                for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-                    int oi[4]; float ci[4]; bool ok[4]; float4 d[4], q[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int i = i0 + v * SLOTS + slot;
-                        ok[v] = i < cnt;
-                        const int src = gbase + (ok[v] ? i : 0);
-                        oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
-                    }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (ok[v]) {
-                            d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
-                            q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
-                        }
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (ok[v]) {
-                            const float j0 = fmaf(ci[v], w.x, psend.x) + q[v].x, j1 = fmaf(ci[v], w.y, psend.y) + q[v].y;
-                            const float j2 = fmaf(ci[v], w.z, psend.z) + q[v].z, j3 = fmaf(ci[v], w.w, psend.w) + q[v].w;
-                            const float t0 = (NEG ? j0 < 0.f : j0 > 0.f) ? d[v].x : 0.f, t1 = (NEG ? j1 < 0.f : j1 > 0.f) ? d[v].y : 0.f;
-                            const float t2 = (NEG ? j2 < 0.f : j2 > 0.f) ? d[v].z : 0.f, t3 = (NEG ? j3 < 0.f : j3 > 0.f) ? d[v].w : 0.f;
-                            acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
-                            dw.x = fmaf(ci[v], t0, dw.x); dw.y = fmaf(ci[v], t1, dw.y); dw.z = fmaf(ci[v], t2, dw.z); dw.w = fmaf(ci[v], t3, dw.w);
-                        }
-                }
-            }
-            acc = slot_reduce<SLOTS>(acc); dw = slot_reduce<SLOTS>(dw);
-            if (slot == 0) {
-                *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
-                *(float4*)(a.dw_rows + (size_t)u * EMB + ch) = make_float4(s1 * dw.x, s1 * dw.y, s1 * dw.z, s1 * dw.w);
-            }
+            if (end - beg <= edge_long_threshold(SLOTS)) edge_bwd_send_segment<SLOTS, NEG>(a, s1, L, w, esh, esc, u, beg, end);
         }
     }
 }
@@ -178,6 +274,14 @@ template <int SLOTS>
 __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
     const float s1 = *a.s1;
     if (s1 < 0.f) edge_bwd_send_impl<SLOTS, true>(a, s1); else edge_bwd_send_impl<SLOTS, false>(a, s1);
+}
+__global__ __launch_bounds__(256) void k_edge_bwd_send_long(EdgeArgs a, int thresh) {
+    const float s1 = *a.s1;
+    const EdgeLane<4> L;
+    const float4 w = *(const float4*)(a.w_edge + L.ch);
+    const float esh = *a.e_shift, esc = *a.e_scale;
+    if (s1 < 0.f) edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { edge_bwd_send_segment<4, true>(a, s1, L, w, esh, esc, u, beg, end); });
+    else edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { edge_bwd_send_segment<4, false>(a, s1, L, w, esh, esc, u, beg, end); });
 }
 
 // ---------------------------------------------------------------------------------------------------------------

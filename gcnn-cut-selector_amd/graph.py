@@ -73,15 +73,24 @@ class BipartiteGraph:
                                             temp_bytes, _stream(dev)), "gcnn_graph_build")
         # keep the temp alive until the stream has consumed it
         temp.record_stream(torch.cuda.current_stream(dev))
+        # longest segment of either order (one small read-back; building a plan is not on the timed path): lets the edge passes
+        # skip their long-segment launch when the list has no segment that is long for its mean degree
+        self.l_max_deg = self.v_max_deg = 0
+        if n_edges > 0:
+            md = torch.stack([(self.l_ptr[1:] - self.l_ptr[:-1]).max() if n_left else self.l_ptr.new_zeros(()),
+                              (self.v_ptr[1:] - self.v_ptr[:-1]).max() if n_var else self.v_ptr.new_zeros(())]).tolist()
+            self.l_max_deg, self.v_max_deg = int(md[0]), int(md[1])
         self._bind()
 
     @classmethod
-    def from_plan(cls, n_left, n_var, l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef):
-        """Wrap CSR arrays that already exist on the device (SampleStore.batch collates them; no sort runs)."""
+    def from_plan(cls, n_left, n_var, l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef, l_max_deg=0, v_max_deg=0):
+        """Wrap CSR arrays that already exist on the device (SampleStore.batch collates them; no sort runs).
+        l_max_deg / v_max_deg: longest segment of each order if known (0 = unknown)."""
         g = cls.__new__(cls)
         g.n_edges, g.n_left, g.n_var, g.device = int(l_oth.numel()), int(n_left), int(n_var), l_ptr.device
         g.l_ptr, g.l_oth, g.l_coef, g.v_ptr, g.v_oth, g.v_coef = l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef
         g.l_perm = None
+        g.l_max_deg, g.v_max_deg = int(l_max_deg), int(v_max_deg)
         g._bind()
         return g
 
@@ -89,4 +98,5 @@ class BipartiteGraph:
         n_edges = self.n_edges
         self.c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
                             self.l_coef.data_ptr() if n_edges else 0, self.v_ptr.data_ptr(),
-                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0)
+                            self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0,
+                            self.l_max_deg, self.v_max_deg)

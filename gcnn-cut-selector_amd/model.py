@@ -107,7 +107,10 @@ class _InferenceSession:
             self.layouts[key] = lay
         return lay
 
-    def run(self, inputs, want_order):
+    def run(self, inputs, want_order, timings=None):
+        """`timings` (optional dict): filled with the host-side phases in seconds (tools/latency.py)."""
+        import time
+        t0 = time.perf_counter()
         c, cei, cef, v, k, kei, kef, n_cons, n_vars, n_cuts = inputs
         c, v, k = np.asarray(c), np.asarray(v), np.asarray(k)
         cei, kei, cef, kef = np.asarray(cei), np.asarray(kei), np.asarray(cef), np.asarray(kef)
@@ -144,13 +147,18 @@ class _InferenceSession:
                            (in_off[7], kef, np.float32)):
             if a.size:
                 np.copyto(buf[off:off + 4 * a.size].view(dt).reshape(a.shape), a, casting="unsafe")
+        t1 = time.perf_counter()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)
             _lib.check(_lib.lib().gcnn_infer(C.byref(dims), C.c_void_p(self.model._flat.data_ptr()),
                                             C.c_void_p(self.pin_in.data_ptr()), C.c_void_p(self.pin_out.data_ptr()),
                                             C.c_void_p(self.arena.data_ptr()), self.arena.numel(), int(want_order),
                                             C.c_void_p(stream.cuda_stream)), "gcnn_infer")
+            t2 = time.perf_counter()
             stream.synchronize()
+        t3 = time.perf_counter()
+        if timings is not None:
+            timings.update(pack=t1 - t0, enqueue=t2 - t1, wait=t3 - t2)
         out = self.out_np
         flags = out[out_off[2]:out_off[2] + 16].view(np.int32)
         if flags[0]:
@@ -535,16 +543,26 @@ class GCNN:
                 return i, scale_name.rsplit("/", 1)[0]
         return None
 
+    # Below this many cuts the descending stable ranking is done on the host (a stable NumPy argsort of a few dozen floats takes
+    # ~2 us; the device ranking kernel costs a launch plus a dependent kernel in the chain: ~10 us end to end, tools/latency.py)
+    HOST_RANK_MAX = 1024
+
     def score_state(self, inputs, rank=False):
         """Scores of ONE sampled state given as host arrays (the SCIP plugins' call, model_evaluator.py:84-111), through the
         single-call path gcnn_infer: one upload, a three-launch graph plan, the inference forward pass, one download.
         Returns a `ScoreArray` (ndarray with `.numpy()`); with `rank=True` its `.rankings` holds the cut indices in descending
-        score order (ties in index order).  States the specialised plan declines (edge lists not sorted by row, more than
+        score order (ties in index order): computed by the device ranking kernel for more than HOST_RANK_MAX cuts or with
+        `rank="device"`, else by a stable argsort on the host (faster for a few dozen cuts).  States the specialised plan declines (edge lists not sorted by row, more than
         32,768 variables, ...) run through `prepare` + the general forward pass instead; results are identical."""
         if self._session is None:
             self._session = _InferenceSession(self)
         try:
-            return self._session.run(inputs, rank)
+            n_cuts = int(np.asarray(inputs[4]).shape[0])
+            on_device = bool(rank) and (rank == "device" or n_cuts > self.HOST_RANK_MAX)
+            scores = self._session.run(inputs, on_device)
+            if rank and not on_device:
+                scores.rankings = np.argsort(-np.asarray(scores), kind="stable").astype(np.int32)
+            return scores
         except _UseGeneralPath:
             with torch.no_grad():
                 scores = self.call(inputs, False).numpy().view(ScoreArray)

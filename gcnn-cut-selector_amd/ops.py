@@ -64,7 +64,8 @@ def conv_edge_fwd(graph: BipartiteGraph, recv_is_left: bool, pl, pr, w_edge, e_s
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().gcnn_conv_edge_fwd(_ptr(ptr), _ptr(oth), _ptr(coef), n_recv, graph.n_edges, _ptr(p_recv),
                                                  _ptr(p_oth), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale), _ptr(s1),
-                                                 _ptr(out), _ptr(nrows), _stream(dev)), "gcnn_conv_edge_fwd")
+                                                 _ptr(out), _ptr(nrows), graph.l_max_deg if recv_is_left else graph.v_max_deg,
+                                                 _stream(dev)), "gcnn_conv_edge_fwd")
     return (out, nrows) if save else out
 
 
@@ -84,7 +85,8 @@ def conv_edge_bwd(graph: BipartiteGraph, recv_is_left: bool, nrows, pl, pr, w_ed
         rows = torch.zeros((max(n_send, 1), EMB), dtype=torch.float32, device=dev)  # per-sender shares of d w_edge
         _lib.check(lib.gcnn_conv_edge_bwd_send(_ptr(sptr), _ptr(soth), _ptr(scoef), n_send, graph.n_edges, _ptr(p_send),
                                                _ptr(p_recv), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale), _ptr(s1), _ptr(d_s),
-                                               _ptr(d_send), _ptr(rows), _stream(dev)), "gcnn_conv_edge_bwd_send")
+                                               _ptr(d_send), _ptr(rows), graph.v_max_deg if recv_is_left else graph.l_max_deg,
+                                               _stream(dev)), "gcnn_conv_edge_bwd_send")
     d_pl, d_pr = (d_recv, d_send) if recv_is_left else (d_send, d_recv)
     return d_pl, d_pr, rows.sum(0)
 

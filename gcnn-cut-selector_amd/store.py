@@ -53,6 +53,7 @@ class SampleStore:
         self._parts = {k: [] for k in ("cons_feats", "var_feats", "cut_feats", "improvements")}
         self._gparts = [{f: [] for f in _GRAPH_FIELDS} for _ in range(2)]
         self._sizes = [[] for _ in range(5)]
+        self._maxdeg = [[[], []] for _ in range(2)]    # per edge set: longest by-left / by-variable segment of every sample
         self._final = False
         self._ring, self._ring_pos = [], 0
 
@@ -110,6 +111,11 @@ class SampleStore:
         for slot, (g, nl, ne) in enumerate(((g1, n_cons, n_e1), (g2, n_cuts, n_e2))):
             for f, t in _localise(g, nl, n_vars, ne, dev).items():
                 self._gparts[slot][f].append(t)
+            for side, (ptr, n) in enumerate(((g.l_ptr, nl), (g.v_ptr, n_vars))):   # longest segment per sample and order
+                deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
+                sid = torch.repeat_interleave(torch.arange(len(samples), device=dev), torch.from_numpy(np.asarray(n, np.int64)).to(dev))
+                self._maxdeg[slot][side].append(torch.zeros(len(samples), dtype=torch.int64, device=dev)
+                                                .scatter_reduce_(0, sid, deg, "amax").cpu().numpy())
         for kind, n in enumerate((n_cons, n_vars, n_cuts, n_e1, n_e2)):
             self._sizes[kind].append(np.asarray(n, np.int64))
 
@@ -126,7 +132,8 @@ class SampleStore:
                        for g in self._gparts]
         self.sizes = np.stack([np.concatenate(s) if s else np.zeros(0, np.int64) for s in self._sizes])   # [5, n]
         self.offsets = np.concatenate([np.zeros((5, 1), np.int64), np.cumsum(self.sizes, axis=1)], axis=1)
-        self._parts = self._gparts = self._sizes = None
+        self.max_deg = [[np.concatenate(m) if m else np.zeros(0, np.int64) for m in per_set] for per_set in self._maxdeg]
+        self._parts = self._gparts = self._sizes = self._maxdeg = None
         self._final = True
         return self
 
@@ -213,7 +220,8 @@ class SampleStore:
         for slot, nl in enumerate((n_c, n_k)):
             graphs.append(BipartiteGraph.from_plan(
                 nl, n_v, view(f"{slot}.l_ptr"), view(f"{slot}.l_oth"), f32(f"{slot}.l_coef", -1), view(f"{slot}.v_ptr"),
-                view(f"{slot}.v_oth"), f32(f"{slot}.v_coef", -1)))
+                view(f"{slot}.v_oth"), f32(f"{slot}.v_coef", -1),
+                l_max_deg=int(self.max_deg[slot][0][ids].max()), v_max_deg=int(self.max_deg[slot][1][ids].max())))
         batch = Batch(f32("cons_feats", n_c, 4), f32("var_feats", n_v, 14), f32("cut_feats", n_k, 6), graphs[0], graphs[1])
         sizes = self.sizes[:, ids]
         return StoreBatch(batch, sizes[_K_CONS].astype(np.int32), sizes[_K_VAR].astype(np.int32),

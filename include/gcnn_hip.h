@@ -56,6 +56,9 @@ typedef struct gcnn_graph {
     const int32_t* v_ptr;   /* [n_var+1]   segment offsets, edges grouped by variable node */
     const int32_t* v_oth;   /* [E]         left index of each edge, by-variable order */
     const float*   v_coef;  /* [E]         raw edge feature, by-variable order */
+    int32_t l_max_deg;      /* longest by-left segment, 0 = unknown.  Edge passes give segments that are long for the list's */
+    int32_t v_max_deg;      /* longest by-variable segment, 0 = unknown.  mean degree a wave of their own in an extra launch,
+                               which is skipped when the list is known to hold none. */
 } gcnn_graph;
 
 /* ---- graph plan: COO -> receiver-sorted CSR in both orders -------------------------------------------------
@@ -127,13 +130,14 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  *           gradient of feature_module_edge's kernel, model.py:490-492). */
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
-                       const float* e_scale, const float* s1, float* s_out, float* n_rows /* optional */, void* stream);
+                       const float* e_scale, const float* s1, float* s_out, float* n_rows /* optional */,
+                       int32_t max_degree /* longest segment, 0 = unknown */, void* stream);
 int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* s1, int32_t n_recv, float* d_p_recv,
                             void* stream);
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send, int32_t n_edges,
                             const float* p_send, const float* p_recv, const float* w_edge, const float* e_shift,
                             const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
-                            void* stream);
+                            int32_t max_degree /* longest segment, 0 = unknown */, void* stream);
 
 /* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
  * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied

@@ -38,6 +38,8 @@ def test_concrete_function_matches_oracle_and_general_path(dev, problem):
         assert np.array_equal(q.numpy(), general)                       # same plan (stable order), same kernels: same bits
         want = sorted(range(len(q)), key=lambda x: q[x], reverse=True)  # model_evaluator.py:110
         assert list(q.rankings) == want
+        qd = f(inp, False, rank="device")                                # the device ranking kernel (default above 1,024 cuts)
+        assert np.array_equal(qd.numpy(), q.numpy()) and list(qd.rankings) == want
         # float64 / int64 host arrays as get_state produces them (utils.py:35-238): converted while packing
         q64 = f(tuple(np.asarray(a, np.float64) if np.asarray(a).dtype.kind == "f" else np.asarray(a, np.int64) if hasattr(a, "shape") else a
                       for a in inp), False)
@@ -77,7 +79,7 @@ def test_score_state_edge_cases(dev):
     kvals[krows == 5] = kvals[krows == 2]
     inp = (rng.standard_normal((C, 4)).astype(f32), np.stack([rows, cols]).astype(i32), rng.standard_normal(200).astype(f32).reshape(-1, 1),
            rng.standard_normal((V, 14)).astype(f32), cut, np.stack([krows, kcols]).astype(i32), kvals.reshape(-1, 1), C, V, K)
-    q = m.score_state(inp, rank=True)
+    q = m.score_state(inp, rank="device")
     np.testing.assert_allclose(q.numpy(), _oracle(params, inp), rtol=1e-4, atol=1e-4)
     with torch.no_grad():
         assert np.array_equal(q.numpy(), m(inp, False).numpy())

@@ -143,7 +143,8 @@ def test_conv_edge_fwd_bwd(dev, shape, recv_is_left, hub):
     f = lambda t: t.float().reshape(-1).to(dev) if t.dim() == 0 else t.float().to(dev)
     args = (f(pl), f(pr), f(w), f(esh), f(esc), f(s1))
     s, saved = ops.conv_edge_fwd(graph, recv_is_left, *args, save=True)
-    _close(ops.conv_edge_fwd(graph, recv_is_left, *args), s, rtol=0, atol=0, what="inference variant")
+    # the inference variant may give a segment more lanes (small graphs: a wave or a block per segment): another summation order
+    _close(ops.conv_edge_fwd(graph, recv_is_left, *args), s.double().cpu(), rtol=1e-5, atol=1e-5, what="inference variant")
     pl_, pr_, w_ = pl.clone().requires_grad_(), pr.clone().requires_grad_(), w.clone().requires_grad_()
     want, _, _ = _edge_reference(ei, coef, pl_, pr_, w_, esh, esc, s1, n_recv, side)
     _close(s, want, what="edge forward")

@@ -19,9 +19,14 @@ for prob in ["setcov", "combauc", "capfac", "indset"]:
         t0 = time.perf_counter()
         with torch.no_grad(): g = m(inp, False).numpy()
         t_gen.append(time.perf_counter() - t0)
+    tm = {"pack": [], "enqueue": [], "wait": []}
+    for _ in range(30):
+        d = {}; m._session.run(inp, False, d)
+        for k_ in tm: tm[k_].append(d[k_])
     with _lib.launch_profile() as prof:
-        f(inp, False, rank=True)
+        f(inp, False)
     dev_us = sum(ms for _, ms in prof.launches) * 1e3
     print(f"{prob:8s} cuts={inp[9]:4d} E={inp[1].shape[1] + inp[5].shape[1]:6d}  gcnn_infer end-to-end {med(t_fast):.3f} ms  (+ranking {med(t_rank):.3f} ms)  "
           f"general path (prepare + forward) {med(t_gen):.3f} ms   kernels: {len(prof.launches)} launches, {dev_us:.0f} us under event brackets")
+    print(f"          host phases: pack {med(tm['pack']) * 1e3:.0f} us, enqueue (copies + {len(prof.launches)} launches) {med(tm['enqueue']) * 1e3:.0f} us, wait for the stream {med(tm['wait']) * 1e3:.0f} us")
     print("          " + "  ".join(f"{n}:{ms * 1e3:.1f}" for n, ms in prof.launches))
