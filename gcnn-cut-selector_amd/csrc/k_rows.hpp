@@ -70,11 +70,12 @@ __device__ __forceinline__ void rt_gemm(const RTile& t, float scale, const float
                 const float4 w4 = *(const float4*)(wl + (16 * mo + m) * LDW + 16 * mt + 4 * g);
                 av[mo][0] = w4.x; av[mo][1] = w4.y; av[mo][2] = w4.z; av[mo][3] = w4.w;
             }
-        } else {
+        } else {   // forward matrices are staged k-interleaved (stage_lds<..., true>): W[4q..4q+3][o] are four consecutive floats
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mo = 0; mo < 4; ++mo) av[mo][i] = wl[(16 * mt + 4 * g + i) * LDW + 16 * mo + m];
+            for (int mo = 0; mo < 4; ++mo) {
+                const float4 w4 = *(const float4*)(wl + ((4 * mt + g) * 64 + 16 * mo + m) * 4);
+                av[mo][0] = w4.x; av[mo][1] = w4.y; av[mo][2] = w4.z; av[mo][3] = w4.w;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,25 +138,45 @@ __device__ __forceinline__ void rt_clear_unless(RTile& o, bool ok) {    // rows 
         for (int i = 0; i < 4; ++i) o.v[m][i] = ok ? o.v[m][i] : 0.f;
 }
 
-// Stage NM 64x64 matrices ([64][LDW] each) and NV 64-float vectors (nullptr -> zeros) into LDS: every global load is
-// issued before the first LDS write, so a block pays ONE round trip for all of them.
-template <int NM, int NV, int NT>
+// Stage NM 64x64 matrices (one [64][LDW]-sized slot each) and NV 64-float vectors (nullptr -> zeros) into LDS: every global
+// load is issued before the first LDS write, so a block pays ONE round trip for all of them.
+// K4 = false: row-major with padded rows [64][LDW] -- what the backward products (x @ W^T: rt_gemm<true>) read as float4.
+// K4 = true : k-interleaved [16][64][4] -- element W[k][o] at ((k>>2)*64 + o)*4 + (k&3) -- so that the forward products
+//             (x @ W: rt_gemm<false>), whose A operand needs W[4q..4q+3][o] per lane, also read one float4 per four MFMAs
+//             (row-major would take four scalar LDS reads, each waited for; 16 consecutive lanes read 256 contiguous bytes).
+template <int NM, int NV, int NT, bool K4 = false>
 __device__ __forceinline__ void stage_lds(float* smem, const float* const (&w)[NM], const float* const (&v)[NV]) {
     constexpr int PER = 1024 / NT;   // float4 per thread per matrix: 4 (256 threads) or 2 (512)
     float4 tmp[NM][PER];
     float vec[NV];
+    if (K4) {   // thread -> column o = t & 63 and row quads q = (t >> 6) + (NT/64)*i: four coalesced scalar loads per quad
 #pragma unroll
-    for (int wi = 0; wi < NM; ++wi)
+        for (int wi = 0; wi < NM; ++wi)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) tmp[wi][i] = *(const float4*)(w[wi] + (size_t)(i * NT + threadIdx.x) * 4);
+            for (int i = 0; i < PER; ++i) {
+                const int q = (threadIdx.x >> 6) + (NT / 64) * i, o = threadIdx.x & 63;
+                const float* src = w[wi] + (size_t)(4 * q) * 64 + o;
+                tmp[wi][i] = make_float4(src[0], src[64], src[128], src[192]);
+            }
+    } else {
+#pragma unroll
+        for (int wi = 0; wi < NM; ++wi)
+#pragma unroll
+            for (int i = 0; i < PER; ++i) tmp[wi][i] = *(const float4*)(w[wi] + (size_t)(i * NT + threadIdx.x) * 4);
+    }
 #pragma unroll
     for (int vi = 0; vi < NV; ++vi) vec[vi] = (threadIdx.x < 64 && v[vi]) ? v[vi][threadIdx.x] : 0.f;
 #pragma unroll
     for (int wi = 0; wi < NM; ++wi)
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int idx = i * NT + threadIdx.x;
-            *(float4*)(smem + wi * 64 * LDW + (idx >> 4) * LDW + (idx & 15) * 4) = tmp[wi][i];
+            if (K4) {
+                const int q = (threadIdx.x >> 6) + (NT / 64) * i, o = threadIdx.x & 63;
+                *(float4*)(smem + wi * 64 * LDW + (q * 64 + o) * 4) = tmp[wi][i];
+            } else {
+                const int idx = i * NT + threadIdx.x;
+                *(float4*)(smem + wi * 64 * LDW + (idx >> 4) * LDW + (idx & 15) * 4) = tmp[wi][i];
+            }
         }
     if (threadIdx.x < 64) {
 #pragma unroll
@@ -184,29 +205,29 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
     float* vecs = smem + NM * 64 * LDW;
     float* w1s = smem + ROWS_LDS_FLOATS(NM, NV);   // first-layer kernel [F][64], bias b1 in vecs[0]
     int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
-    float xv[F];
-    auto load_ops = [&](int t) {
+    float xv[F], xn_[F];   // operands of the current tile / of the wave's next tile (requested before the current one is computed)
+    auto load_ops = [&](float (&dst)[F], int t) {
         const int row = t * 16 + j;
 #pragma unroll
-        for (int f = 0; f < F; ++f) xv[f] = row < a.n ? a.x[(size_t)row * F + f] : 0.f;
+        for (int f = 0; f < F; ++f) dst[f] = row < a.n ? a.x[(size_t)row * F + f] : 0.f;
     };
-    load_ops(tile);
+    load_ops(xv, tile);
     if (NPROJ == 2) {
         const float* const w[3] = {a.w2, a.wp[0], a.wp[1]};
         const float* const v[4] = {a.b1, a.b2, a.bp[0], a.bp[1]};
-        stage_lds<3, 4, NT>((float*)smem, w, v);
+        stage_lds<3, 4, NT, true>((float*)smem, w, v);
     } else {
         const float* const w[2] = {a.w2, a.wp[0]};
         const float* const v[3] = {a.b1, a.b2, a.bp[0]};
-        stage_lds<2, 3, NT>((float*)smem, w, v);
+        stage_lds<2, 3, NT, true>((float*)smem, w, v);
     }
     for (int i = threadIdx.x; i < F * 64; i += NT) w1s[i] = a.w1[i];
     float shift[F], scale[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) { shift[f] = a.shift[f]; scale[f] = a.scale[f]; }
     __syncthreads();
-    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
-        if (!first) load_ops(tile);
+    for (; tile < ntile; tile += nblk * NWAVES) {
+        load_ops(xn_, tile + nblk * NWAVES);   // past the last tile: no loads
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile o, t;
@@ -235,6 +256,8 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
             rt_bias<false>(o, vecs + (2 + k) * 64, g);
             rt_store(o, a.po[k], row, ok, g);
         }
+#pragma unroll
+        for (int f = 0; f < F; ++f) xv[f] = xn_[f];
     }
 }
 struct EmbGroupArgs { int blk0[4]; EmbArgs v, c, k; };   // variables (F=14, two projections), constraints (4), cuts (6)
@@ -286,32 +309,32 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
     int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
-    RTile s_in, xr;
-    int seg0 = 0, seg1 = 0;
-    auto load_ops = [&](int t) {
+    struct Ops { RTile s_in, xr; int seg0, seg1; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
+    auto load_ops = [&](Ops& d, int t) {
         const int row = t * 16 + j;
         const bool ok = row < a.n;
-        rt_load(s_in, a.s, row, ok, g);
-        rt_load(xr, a.xrecv, row, ok, g);
-        seg0 = ok ? a.seg_ptr[row] : 0; seg1 = ok ? a.seg_ptr[row + 1] : 0;
+        rt_load(d.s_in, a.s, row, ok, g);
+        rt_load(d.xr, a.xrecv, row, ok, g);
+        d.seg0 = ok ? a.seg_ptr[row] : 0; d.seg1 = ok ? a.seg_ptr[row + 1] : 0;
     };
-    load_ops(tile);
+    load_ops(cur, tile);
     {
         const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
         const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, TAIL != CF_PROJ ? a.ws : nullptr};
-        stage_lds<5, 5, NT>(smem, w, v);
+        stage_lds<5, 5, NT, true>(smem, w, v);
     }
     const float s2 = *a.s2;
     const float bs = TAIL != CF_PROJ ? *a.bs : 0.f;
     __syncthreads();
-    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
-        if (!first) load_ops(tile);
+    for (; tile < ntile; tile += nblk * NWAVES) {
+        load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
+        const RTile &s_in = cur.s_in, &xr = cur.xr;
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;
         rt_mm<false>(t0, s_in, 1.f, smem, lane);
         {   // + deg * bf
-            const float deg = (float)(seg1 - seg0);
+            const float deg = (float)(cur.seg1 - cur.seg0);
             const float* bfv = lds_here(vecs);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -370,6 +393,7 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
                 if (lane == 0) { slab[EMB] = dbs; slab[EMB + 1] = ls; }
             }
         }
+        cur = nxt;
     }
 }
 template <int NWAVES, int TAIL>
@@ -403,16 +427,16 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
-    RTile in, m0, m1, nr;
-    auto load_ops = [&](int t) {
+    struct Ops { RTile in, m0, m1, nr; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
+    auto load_ops = [&](Ops& d, int t) {
         const int row = t * 16 + j;
         const bool ok = row < a.n;
-        rt_load(in, a.in, row, ok, g);
-        rt_load(m0, a.x_out, row, ok, g);
-        rt_load(m1, a.z1, row, ok, g);
-        rt_load(nr, a.nrows, row, ok, g);
+        rt_load(d.in, a.in, row, ok, g);
+        rt_load(d.m0, a.x_out, row, ok, g);
+        rt_load(d.m1, a.z1, row, ok, g);
+        rt_load(d.nr, a.nrows, row, ok, g);
     };
-    load_ops(tile);
+    load_ops(cur, tile);
     {
         const float* const w[5] = {a.w0, a.w2, a.w1b, a.w1a, a.wf};
         const float* const v[1] = {nullptr};
@@ -420,8 +444,9 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
     }
     const float s2 = *a.s2, s1 = *a.s1;
     __syncthreads();
-    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
-        if (!first) load_ops(tile);
+    for (; tile < ntile; tile += nblk * NWAVES) {
+        load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
+        const RTile &in = cur.in, &m0 = cur.m0, &m1 = cur.m1, &nr = cur.nr;
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;
@@ -446,6 +471,7 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
 #pragma unroll
             for (int i = 0; i < 4; ++i) t1.v[m][i] = s1 * t1.v[m][i] * nr.v[m][i];
         rt_store(t1, a.g_precv, row, ok, g);
+        cur = nxt;
     }
 }
 
@@ -466,22 +492,23 @@ __device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
-    RTile ia, ib, ad, mk;
-    auto load_ops = [&](int t) {
+    struct Ops { RTile ia, ib, ad, mk; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
+    auto load_ops = [&](Ops& d, int t) {
         const int row = t * 16 + j;
         const bool ok = row < a.n;
-        rt_load(ia, a.in_a, row, ok, g);
-        if (HAS_INB) rt_load(ib, a.in_b, row, ok, g);
-        rt_load(ad, a.add, row, ok, g);
-        rt_load(mk, a.x, row, ok, g);
+        rt_load(d.ia, a.in_a, row, ok, g);
+        if (HAS_INB) rt_load(d.ib, a.in_b, row, ok, g);
+        rt_load(d.ad, a.add, row, ok, g);
+        rt_load(d.mk, a.x, row, ok, g);
     };
-    load_ops(tile);
+    load_ops(cur, tile);
     const float* const v[1] = {nullptr};
     if (HAS_INB) { const float* const w[3] = {a.wa, a.w2, a.wb}; stage_lds<3, 1, NT>(smem, w, v); }
     else { const float* const w[2] = {a.wa, a.w2}; stage_lds<2, 1, NT>(smem, w, v); }
     __syncthreads();
-    for (bool first = true; tile < ntile; tile += nblk * NWAVES, first = false) {
-        if (!first) load_ops(tile);
+    for (; tile < ntile; tile += nblk * NWAVES) {
+        load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
+        const RTile &ia = cur.ia, &ib = cur.ib, &ad = cur.ad, &mk = cur.mk;
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;
@@ -495,6 +522,7 @@ __device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, i
         rt_store(t0, a.g_x, row, ok, g);
         rt_mm<true>(t1, t0, 1.f, smem + 64 * LDW, lane);
         rt_store(t1, a.g_e1, row, ok, g);
+        cur = nxt;
     }
 }
 
