@@ -100,7 +100,28 @@ static inline bool edge_needs_long_pass(int slots, int max_deg) {
 }
 static inline int edge_long_grid(int n_own) { return std::max(1, std::min(cdiv(n_own, 4), MAX_GRID)); }
 // forward (owner = receiver); `count` also emits the N rows (active edges per receiver and channel) for the backward pass
-static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool count, hipStream_t st) {
+static int launch_plan_place(const IplanArgs& ia, hipStream_t st);
+static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool count, hipStream_t st, const IplanArgs* plan = nullptr) {
+    if (plan) {   // single-state inference: the plan's place step rides in this launch as extra blocks (k_infer_s2)
+        const bool blockseg = a.n_own <= 1024 && n_edges >= 48ll * a.n_own;
+        if (!count && a.n_own <= 16384 && plan->n_vars <= IPLAN_FUSE_MAX_VARS) {
+            const int edge_blocks = a.n_own <= 0 ? 0 : (blockseg ? a.n_own : std::min(cdiv(a.n_own, 4), MAX_GRID));
+            const int place_blocks = std::max(1, std::min(cdiv(plan->s[0].n_edges, 256), 256));   // one returning atomic per thread
+            static PerDeviceOnce attr;
+            if (attr.first()) {
+                HIPCHK(hipFuncSetAttribute((const void*)k_infer_s2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (IPLAN_MAX_VARS + 1)));
+                HIPCHK(hipFuncSetAttribute((const void*)k_infer_s2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (IPLAN_MAX_VARS + 1)));
+            }
+            ProfScope prof("k_infer_s2 (conv v->c edge pass + plan: place)", st);
+            const size_t smem = 4 * (size_t)(plan->n_vars + 1);
+            if (blockseg) hipLaunchKernelGGL(k_infer_s2<true>, dim3(edge_blocks + place_blocks), dim3(256), smem, st, a, *plan, edge_blocks);
+            else hipLaunchKernelGGL(k_infer_s2<false>, dim3(edge_blocks + place_blocks), dim3(256), smem, st, a, *plan, edge_blocks);
+            LAUNCHCHK();
+            return 0;
+        }
+        int rc = launch_plan_place(*plan, st);   // a graph too large for the fused form: the step as a launch of its own
+        if (rc) return rc;
+    }
     if (a.n_own <= 0) return 0;
     if (count && !a.cnt_rows) return GCNN_E_BADARG;
     // inference on a small graph (one sampled state): latency, not lane efficiency, decides -- a whole wave per segment needs no
@@ -146,6 +167,15 @@ static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, int max_deg, hip
         hipLaunchKernelGGL(k_edge_bwd_send_long, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
         LAUNCHCHK();
     }
+    return 0;
+}
+
+static int launch_plan_place(const IplanArgs& ia, hipStream_t st) {
+    static PerDeviceOnce attr;
+    if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_iplan_place, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (IPLAN_MAX_VARS + 1)));
+    ProfScope prof("k_iplan_place", st);
+    hipLaunchKernelGGL(k_iplan_place, dim3(std::max(1, std::min(cdiv(ia.s[0].n_edges, 1024), 64))), dim3(1024), 4 * (size_t)(ia.n_vars + 1), st, ia);
+    LAUNCHCHK();
     return 0;
 }
 
@@ -437,32 +467,52 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
     }
     return nwaves;
 }
-#define ROWS_LAUNCH(NAME, KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ARGS)                                               \
+#define ROWS_LAUNCH(NAME, KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ...)                                                \
     do {                                                                                                                \
         ProfScope prof(NAME, ST);                                                                                       \
         static PerDeviceOnce attr;                                                                                      \
         if (attr.first()) {                                                                                             \
-            HIPCHK(hipFuncSetAttribute((const void*)KERNEL8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
-            HIPCHK(hipFuncSetAttribute((const void*)KERNEL4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+            HIPCHK(hipFuncSetAttribute((const void*)KERNEL8, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));  \
+            HIPCHK(hipFuncSetAttribute((const void*)KERNEL4, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));  \
         }                                                                                                               \
-        if ((NWAVES) == 8) hipLaunchKernelGGL(KERNEL8, dim3(GRID), dim3(512), SMEM, ST, ARGS);                          \
-        else hipLaunchKernelGGL(KERNEL4, dim3(GRID), dim3(256), SMEM, ST, ARGS);                                        \
+        if ((NWAVES) == 8) hipLaunchKernelGGL(KERNEL8, dim3(GRID), dim3(512), SMEM, ST, __VA_ARGS__);                   \
+        else hipLaunchKernelGGL(KERNEL4, dim3(GRID), dim3(256), SMEM, ST, __VA_ARGS__);                                 \
         LAUNCHCHK();                                                                                                    \
     } while (0)
 
-static int launch_embed_fwd(EmbGroupArgs& m, hipStream_t st) {
+// `plan` (single-state inference, gcnn_infer): the plan's count step rides in this launch as extra blocks
+static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
     const int n[3] = {m.v.n, m.c.n, m.k.n}, ns[3] = {4, 3, 3};
     const int nwaves = rows_blocks(n, ns, 3, m.blk0);
+    if (plan) {
+        const int nt = nwaves * 64;
+        plan->blocks0 = std::min(cdiv(plan->s[0].n_edges + 1, nt), 32);   // few blocks, looping: they hold a CU slot of this launch's size
+        plan->blocks1 = std::min(cdiv(plan->s[1].n_edges + 1, nt), 8);
+        const int grid = m.blk0[3] + plan->blocks0 + plan->blocks1;
+        ROWS_LAUNCH("k_infer_s1 (embeddings + plan: count)", k_infer_s1<8>, k_infer_s1<4>, nwaves, grid, EMB_LDS_FLOATS * sizeof(float), st, m, *plan);
+        return 0;
+    }
     if (m.blk0[3] == 0) return 0;
     ROWS_LAUNCH("k_embed_fwd", k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3], EMB_LDS_FLOATS * sizeof(float), st, m);
     return 0;
 }
-static int launch_conv_fwd(const ConvFArgs& a, int tail, hipStream_t st) {
+static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, hipStream_t st) {
     int blk0[2];
     const int ns = 4;
     const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
-    if (blk0[1] == 0) return 0;
     const size_t smem = ROWS_LDS_FLOATS(5, 5) * sizeof(float);
+    if (plan && tail == CF_PROJ && plan->n_vars <= IPLAN_FUSE_MAX_VARS) {   // the plan's order step rides in this launch
+        const int grid = blk0[1] + std::min(cdiv(plan->n_vars, nwaves * 4), 48);
+        if (grid == 0) return 0;
+        ROWS_LAUNCH("k_infer_s3 (conv row program + plan: order)", k_infer_s3<8>, k_infer_s3<4>, nwaves, grid, smem, st, a, *plan, blk0[1]);
+        return 0;
+    }
+    if (plan && tail == CF_PROJ && plan->n_vars > 0) {   // many variables: the order step wants every lane group resident at once
+        ProfScope prof("k_iplan_order", st);
+        hipLaunchKernelGGL(k_iplan_order, dim3(std::min(cdiv(plan->n_vars, 16), 2048)), dim3(256), 0, st, *plan);
+        LAUNCHCHK();
+    }
+    if (blk0[1] == 0) return 0;
     if (tail == CF_LOSS) ROWS_LAUNCH("k_conv_fwd<loss>", (k_conv_fwd<8, CF_LOSS>), (k_conv_fwd<4, CF_LOSS>), nwaves, blk0[1], smem, st, a);
     else if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout>", (k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
     else ROWS_LAUNCH("k_conv_fwd<proj>", (k_conv_fwd<8, CF_PROJ>), (k_conv_fwd<4, CF_PROJ>), nwaves, blk0[1], smem, st, a);
@@ -508,11 +558,11 @@ static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
 // consumes X': the next convolution's projection (wt, bt -> t_out) or the readout
 struct LossHead { const float* targets; float scale; float* g_o1; float* partial; };   // CF_LOSS extras
 static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, const float* wt, const float* bt,
-                        float* t_out, int tail, float* scores, const LossHead* head) {
+                        float* t_out, int tail, float* scores, const LossHead* head, const IplanArgs* plan = nullptr) {
     int rc;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
     e.out = c.S; e.cnt_rows = c.N;
-    if ((rc = launch_edge_fwd(e, c.ne, c.recv_left ? c.g->l_max_deg : c.g->v_max_deg, save, st))) return rc;
+    if ((rc = launch_edge_fwd(e, c.ne, c.recv_left ? c.g->l_max_deg : c.g->v_max_deg, save, st, plan))) return rc;
     ConvFArgs a; memset(&a, 0, sizeof(a));
     a.n = c.recv_left ? c.nl : c.nv;
     a.s = c.S; a.seg_ptr = e.seg_ptr; a.wf = p + poff(c.pbase + C_WF); a.bf = p + poff(c.pbase + C_BF); a.a_out = save ? c.A : nullptr;
@@ -523,7 +573,7 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
     a.wt = wt; a.bt = bt; a.t_out = t_out;
     if (tail != CF_PROJ) { a.ws = p + poff(P_OUT + 2); a.bs = p + poff(P_OUT + 3); a.scores = scores; }
     if (tail == CF_LOSS) { a.targets = head->targets; a.loss_scale = head->scale; a.g_o1 = head->g_o1; a.head_partial = head->partial; }
-    return launch_conv_fwd(a, tail, st);
+    return launch_conv_fwd(a, tail, plan, st);
 }
 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
@@ -549,7 +599,7 @@ static int check_common(const gcnn_dims* d, const float* params, const gcnn_grap
 static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                         const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                         size_t workspace_floats, float* scores, bool save, const float* targets, float loss_scale,
-                        hipStream_t st) {
+                        hipStream_t st, IplanArgs* plan = nullptr) {
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
@@ -571,12 +621,12 @@ static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_fe
         m.c.wp[0] = p + poff(P_CONV0 + C_WL); m.c.bp[0] = p + poff(P_CONV0 + C_BL); m.c.po[0] = A.PL1;
         emb(m.k, cut_feats, P_CUT, A.E1k, A.Xk, d->n_cuts);    // cuts: E1 -> Xk -> PL3
         m.k.wp[0] = p + poff(P_CONV2 + C_WL); m.k.bp[0] = p + poff(P_CONV2 + C_BL); m.k.po[0] = A.PL3;
-        if ((rc = launch_embed_fwd(m, st))) return rc;
+        if ((rc = launch_embed_fwd(m, plan, st))) return rc;
     }
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     // updated constraints -> left projection of conv c->v
-    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, CF_PROJ, nullptr, nullptr))) return rc;
+    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, CF_PROJ, nullptr, nullptr, plan))) return rc;
     // updated variables -> right projection of conv v->k
     if ((rc = conv_forward(p, cv[1], save, st, p + poff(P_CONV2 + C_WR), nullptr, A.PR3, CF_PROJ, nullptr, nullptr))) return rc;
     // updated cuts -> readout (model.py:206-208, 299-300)
@@ -641,32 +691,15 @@ extern "C" int gcnn_infer(const gcnn_dims* d, const float* params, const void* h
     ia.n_vars = V; ia.vcount = zero; ia.cursor = zero + V; ia.flags = zero + 2 * V;
     ia.v_ptr = (int*)(A + L.dev_off[2]); ia.v_pos = (int*)(A + L.dev_off[3]); ia.v_oth = (int*)(A + L.dev_off[4]);
     ia.v_coef = (float*)(A + L.dev_off[5]); ia.cons_coef = (const float*)(A + L.in_off[3]);
-    ia.blocks0 = cdiv(E1 + 1, 256);
-    {
-        ProfScope prof("k_iplan_count", st);
-        hipLaunchKernelGGL(k_iplan_count, dim3(ia.blocks0 + cdiv(E2 + 1, 256)), dim3(256), 0, st, ia);
-        LAUNCHCHK();
-    }
-    {
-        static PerDeviceOnce attr;
-        if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_iplan_place, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (IPLAN_MAX_VARS + 1)));
-        ProfScope prof("k_iplan_place", st);
-        hipLaunchKernelGGL(k_iplan_place, dim3(std::max(1, std::min(cdiv(E1, 1024), 64))), dim3(1024), 4 * (size_t)(V + 1), st, ia);
-        LAUNCHCHK();
-    }
-    if (V > 0) {
-        ProfScope prof("k_iplan_order", st);
-        hipLaunchKernelGGL(k_iplan_order, dim3(cdiv(V, 16)), dim3(256), 0, st, ia);
-        LAUNCHCHK();
-    }
     gcnn_graph cg, kg; memset(&cg, 0, sizeof(cg)); memset(&kg, 0, sizeof(kg));
     cg.l_ptr = ia.s[0].l_ptr; cg.l_oth = ia.s[0].inds + E1; cg.l_coef = ia.cons_coef;       // by-left order = the input lists
     cg.v_ptr = ia.v_ptr; cg.v_oth = ia.v_oth; cg.v_coef = ia.v_coef;
     kg.l_ptr = ia.s[1].l_ptr; kg.l_oth = ia.s[1].inds + E2; kg.l_coef = (const float*)(A + L.in_off[7]);
     kg.v_ptr = ia.v_ptr;   // never read: conv v->k gathers by cut only and nothing is differentiated
     float* out = (float*)(A + L.dev_off[6]);
-    rc = gcnn_forward(d, params, (const float*)(A + L.in_off[1]), (const float*)(A + L.in_off[4]), (const float*)(A + L.in_off[5]),
-                      &cg, &kg, (float*)(A + L.dev_off[7]), gcnn_workspace_floats(d), out, 0, stream);
+    // the plan's three steps ride in the forward pass's first three launches (k_infer.hpp)
+    rc = forward_impl(d, params, (const float*)(A + L.in_off[1]), (const float*)(A + L.in_off[4]), (const float*)(A + L.in_off[5]),
+                      &cg, &kg, (float*)(A + L.dev_off[7]), gcnn_workspace_floats(d), out, false, nullptr, 0.f, st, &ia);
     if (rc) return rc;
     if (want_order && K > 0) {
         ProfScope prof("k_rank_scores", st);

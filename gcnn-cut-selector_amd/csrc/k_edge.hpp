@@ -116,14 +116,14 @@ __device__ __forceinline__ void edge_fwd_segment(const EdgeArgs& a, const float 
 }
 
 template <int SLOTS, bool COUNT, bool NEG>
-__device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1) {
+__device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1, const int bid, const int nblk) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const EdgeLane<SLOTS> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
     const int nwork = (a.n_own + RPW - 1) / RPW;  // one work item = one wave's RPW receivers
-    for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
+    for (int item = xcd_remap(bid, nblk) * 4 + wv; item < nwork; item += nblk * 4) {
         const int r = item * RPW + lane / G;
         if (r < a.n_own) {
             const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
@@ -135,20 +135,21 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1)
 template <int SLOTS, bool COUNT>
 __global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
     const float s1 = *a.s1;
-    if (s1 < 0.f) edge_fwd_impl<SLOTS, COUNT, true>(a, s1); else edge_fwd_impl<SLOTS, COUNT, false>(a, s1);
+    if (s1 < 0.f) edge_fwd_impl<SLOTS, COUNT, true>(a, s1, blockIdx.x, gridDim.x);
+    else edge_fwd_impl<SLOTS, COUNT, false>(a, s1, blockIdx.x, gridDim.x);
 }
 
 // Inference on ONE sampled state with long segments (the cut rows of conv v->k: a few dozen cuts of 10-200 nonzeros each): a
 // wave per segment would walk a dozen dependent gather rounds with most of the chip idle.  Here a 4-wave block serves one
 // segment, each wave a contiguous quarter, and the four partial sums are added in a fixed order.
-__global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) {
+__device__ __forceinline__ void edge_fwd_block_body(const EdgeArgs& a, const int bid, const int nblk) {
     __shared__ float4 red[4][16];
     const float s1 = *a.s1;
     const EdgeLane<4> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = blockIdx.x; r < a.n_own; r += gridDim.x) {
+    for (int r = bid; r < a.n_own; r += nblk) {
         const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
         const int chunk = ((end - beg + 3) / 4 + 15) & ~15;
         const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) {
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) { edge_fwd_block_body(a, blockIdx.x, gridDim.x); }
 
 // The rows the main kernel left out (longer than `thresh`), one wave each.  `body(r, beg, end)` is called wave-uniformly.
 template <class Body>
