@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch shi
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
 LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GcnnError(RuntimeError):
@@ -70,7 +70,7 @@ SIGNATURES = {
     "gcnn_linear_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "gcnn_conv_edge_fwd": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "gcnn_conv_edge_bwd_recv": (C.c_int, [_P, _P, _P, _I, _P, _P]),
-    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "gcnn_conv_edge_bwd_send": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_int32), _I, _P]),
     "gcnn_workspace_floats": (_Z, [_DP]),
     "gcnn_forward": (C.c_int, [_DP, _P, _P, _P, _P, _GP, _GP, _P, _Z, _P, _I, _P]),
     "gcnn_infer_layout_for": (C.c_int, [_DP, C.POINTER(InferLayout)]),

@@ -151,10 +151,13 @@ static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool cou
     return 0;
 }
 // backward, sender-ordered (owner = sender)
-static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, int max_deg, hipStream_t st) {
+// *n_parts = rows of a.dw_partial written (one per block of the launch(es)): what k_reduce has to sum into d w_edge
+static int launch_edge_bwd_send(EdgeArgs a, int n_edges, int max_deg, int* n_parts, hipStream_t st) {
+    *n_parts = 0;
     if (a.n_own <= 0) return 0;
     const int slots = edge_slots(a.n_own, n_edges);
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), MAX_GRID);
+    *n_parts = grid;
     {
         ProfScope prof("k_edge_bwd_send", st);
         if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
@@ -164,8 +167,10 @@ static int launch_edge_bwd_send(const EdgeArgs& a, int n_edges, int max_deg, hip
     }
     if (edge_needs_long_pass(slots, max_deg)) {
         ProfScope prof("k_edge_bwd_send_long", st);
+        a.dw_partial += (size_t)grid * EMB;
         hipLaunchKernelGGL(k_edge_bwd_send_long, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
         LAUNCHCHK();
+        *n_parts += edge_long_grid(a.n_own);
     }
     return 0;
 }
@@ -188,7 +193,8 @@ struct Acts {
 struct Work {
     Acts a, g;            // activations and their gradients
     float* partial;       // weight-gradient slabs
-    float* q[3];          // per-sender shares of d w_edge, one [n_send,64] matrix per convolution
+    float* dwp[3];        // per-block partials of d w_edge, one [GCNN_EDGE_DW_PARTS,64] array per convolution
+    float* dwp2[3];       // ... and their pre-reduction to [GCNN_EDGE_DW_PARTS / DW_CHUNK, 64] (k_wgrad's third block type)
     float* nrow[3];          // per receiver and channel: number of active edges
     float* emb_partial[3];
     float* score_partial; int score_nblk;
@@ -220,8 +226,10 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     }
     w->partial = take(wg_slabs(d) * WG_SLAB);
     const size_t nrecv[3] = {C, V, K};
-    const size_t nsend[3] = {V, C, V};
-    for (int i = 0; i < 3; ++i) { w->q[i] = take(nsend[i] * EMB); w->nrow[i] = take(nrecv[i] * EMB); }
+    for (int i = 0; i < 3; ++i) {
+        w->dwp[i] = take((size_t)GCNN_EDGE_DW_PARTS * EMB); w->dwp2[i] = take((size_t)(GCNN_EDGE_DW_PARTS / DW_CHUNK) * EMB);
+        w->nrow[i] = take(nrecv[i] * EMB);
+    }
     const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
     const int femb[3] = {4, 14, 6};
     for (int i = 0; i < 3; ++i) {
@@ -237,7 +245,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 8; }
+int gcnn_abi_version(void) { return 9; }
 
 int gcnn_profile_begin(void) { g_prof.n = 0; g_prof.on = true; return 0; }
 int gcnn_profile_end(int32_t capacity, const char** names, float* ms) {
@@ -426,15 +434,18 @@ int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* 
 }
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send, int32_t n_edges,
                             const float* p_send, const float* p_recv, const float* w_edge, const float* e_shift,
-                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
-                            int32_t max_degree, void* stream) {
-    if (n_send < 0 || n_edges < 0) return GCNN_E_BADARG;
-    if (n_send > 0 && (!seg_ptr || !p_send || !w_edge || !s1 || !e_shift || !e_scale || !d_p_send || !dw_rows)) return GCNN_E_BADARG;
+                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_partial,
+                            int32_t* n_parts, int32_t max_degree, void* stream) {
+    if (n_send < 0 || n_edges < 0 || !n_parts) return GCNN_E_BADARG;
+    if (n_send > 0 && (!seg_ptr || !p_send || !w_edge || !s1 || !e_shift || !e_scale || !d_p_send || !dw_partial)) return GCNN_E_BADARG;
     if (n_edges > 0 && (!oth || !coef || !p_recv || !d_s)) return GCNN_E_BADARG;
     EdgeArgs e; memset(&e, 0, sizeof(e));
     e.seg_ptr = seg_ptr; e.oth = oth; e.coef = coef; e.p_own = p_send; e.p_oth = p_recv; e.w_edge = w_edge; e.s1 = s1;
-    e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_rows = dw_rows; e.n_own = n_send;
-    return launch_edge_bwd_send(e, n_edges, max_degree, (hipStream_t)stream);
+    e.e_shift = e_shift; e.e_scale = e_scale; e.d_s = d_s; e.out = d_p_send; e.dw_partial = dw_partial; e.n_own = n_send;
+    int parts = 0;
+    const int rc = launch_edge_bwd_send(e, n_edges, max_degree, &parts, (hipStream_t)stream);
+    *n_parts = parts;
+    return rc;
 }
 
 }  // extern "C"
@@ -540,7 +551,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     bool recv_left;
     const gcnn_graph* g; int pedge;  // edge PreNorm parameter index (shift; scale = +1)
     float *PL, *PR, *S, *A, *Z1, *OUT;
-    float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *Q;
+    float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *DWP, *DWP2;
     float* N;
 };
 
@@ -579,11 +590,11 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.q[0], w.nrow[0]};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0]};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.q[1], w.nrow[1]};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1]};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.q[2], w.nrow[2]};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2]};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -724,13 +735,14 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
 struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
+    DwRedArgs dw; int ndw;   // d w_edge pre-reductions (one per convolution with edge-gradient partials)
 };
-static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr, const float* d2,
+static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr,
                    int n, float* gw, float* gb, float* g2, float* partial) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
     WgJob& j = jl.wg.job[jl.wg.njobs++];
     const int nb = cdiv(n, jl.wg.rows_per_wave * WG_WAVES);   // blocks = slabs: four chunks each
-    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.d2 = d2; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
+    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
     const float* src = partial + (size_t)jl.nslab * WG_SLAB;
     jl.wg.nblocks += nb; jl.nslab += nb;
     auto rd = [&](const float* s, float* dst, int len) {
@@ -769,21 +781,24 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     const int nr = c.recv_left ? c.nl : c.nv;
     const float* xrecv = c.recv_left ? c.xl : c.xv;
     // the receiver-ordered half (dP_recv) came out of the row program's epilogue; sender-ordered half: gathers dS and P_recv rows
-    // (the ReLU pattern is recomputed), which also yields Q, the per-sender share of d w_edge
+    // (the ReLU pattern is recomputed) and leaves d w_edge as one 64-float partial per block
     EdgeArgs e = conv_edge_args(p, c, !c.recv_left);
-    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_rows = c.Q;
-    if ((rc = launch_edge_bwd_send(e, c.ne, c.recv_left ? c.g->v_max_deg : c.g->l_max_deg, st))) return rc;
+    e.d_s = c.gS; e.out = c.recv_left ? c.gPR : c.gPL; e.dw_partial = c.DWP;
+    int dw_parts = 0;
+    if ((rc = launch_edge_bwd_send(e, c.ne, c.recv_left ? c.g->v_max_deg : c.g->l_max_deg, &dw_parts, st))) return rc;
+    if (dw_parts > 0) {   // DW_CHUNK partial rows per block of the k_wgrad launch, then the usual fixed-order reduction
+        const int k = jl.ndw++;
+        jl.dw.src[k] = c.DWP; jl.dw.dst[k] = c.DWP2; jl.dw.nparts[k] = dw_parts;
+        jl.dw.blk0[k + 1] = jl.dw.blk0[k] + cdiv(dw_parts, DW_CHUNK);
+        add_rd(jl, c.DWP2, grads + poff(c.pbase + C_WE), cdiv(dw_parts, DW_CHUNK), EMB, EMB);
+    }
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
-    float* gwe = grads + poff(c.pbase + C_WE);
-    add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
-    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
-    add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
-    add_wg(jl, c.S, nullptr, c.gA, seg, nullptr, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
-    // Q lives on the sender side: column-summed together with the sender-side projection's job
-    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.recv_left ? nullptr : c.Q, c.nl, grads + poff(c.pbase + C_WL),
-           grads + poff(c.pbase + C_BL), c.recv_left ? nullptr : gwe, w.partial);
-    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.recv_left ? c.Q : nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr,
-           c.recv_left ? gwe : nullptr, w.partial);
+    add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
+    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
+    add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
+    add_wg(jl, c.S, nullptr, c.gA, seg, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
+    add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.nl, grads + poff(c.pbase + C_WL), grads + poff(c.pbase + C_BL), nullptr, w.partial);
+    add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr, nullptr, w.partial);
     return 0;
 }
 
@@ -851,7 +866,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     }
     add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), head_parts, HEAD_SLAB, EMB);
     add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), head_parts, HEAD_SLAB, 1);
-    add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
+    add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
     auto tail = [&](TailBArgs& t, const float* in_a, const float* wa, const float* in_b, const float* wb, float* gx, const float* x,
                     int pb, float* ge1, int n) {
         t.in_a = in_a; t.wa = wa; t.in_b = in_b; t.wb = wb; t.add = gx; t.x = x; t.g_x = gx; t.w2 = p + poff(pb + E_W2);
@@ -899,14 +914,15 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
     }
     for (int i = 0; i < 3; ++i)
-        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
+        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
-    if (jl.wg.nblocks + ea.nblocks > 0) {
+    for (int k = jl.ndw; k < 3; ++k) jl.dw.blk0[k + 1] = jl.dw.blk0[k];
+    if (jl.wg.nblocks + ea.nblocks + jl.dw.blk0[3] > 0) {
         static PerDeviceOnce attr;
         const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default
         if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ProfScope prof("k_wgrad", st);
-        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks), dim3(64 * WG_WAVES), smem, st, jl.wg, ea);
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks + jl.dw.blk0[3]), dim3(64 * WG_WAVES), smem, st, jl.wg, ea, jl.dw);
         LAUNCHCHK();
     }
     const bool fuse_adam = adam && d->n_cons > 0 && d->n_vars > 0 && jl.rdblk > 0;

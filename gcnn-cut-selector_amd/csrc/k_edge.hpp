@@ -23,7 +23,7 @@ struct EdgeArgs {
     const float* w_edge; const float* e_shift; const float* e_scale; const float* s1;
     const float* d_s;                              // send pass: dS of the forward's receivers, gathered by oth like p_oth
     float* out;                                    // S (fwd) / dP_send
-    float* dw_rows;                                // send pass: Q [n_own,64], per-sender share of d w_edge
+    float* dw_partial;                             // send pass: [gridDim.x][64], each block's share of d w_edge (summed by k_reduce)
     float* cnt_rows;                               // fwd (COUNT): N[r] = number of active edges per channel
     int n_own;
 };
@@ -209,11 +209,12 @@ __global__ __launch_bounds__(256) void k_edge_bwd_recv(const float* __restrict__
 // Backward, sender-ordered half.  Segment owner = the SENDING node u; per edge the receiver r = oth[e]:
 //   J_e = (c_e*w + P_send[u]) + P_recv[r]   -- the forward's expression, instruction for instruction: same bits
 //   t_e = [s1*J_e > 0] * dS[r]
-//   dP_send[u] = s1 * sum_{e in seg(u)} t_e          Q[u] = s1 * sum_{e in seg(u)} c_e * t_e   (share of d w_edge)
+//   dP_send[u] = s1 * sum_{e in seg(u)} t_e          d w_edge = s1 * sum_e c_e * t_e   (per-block partials, see edge_dw_block_store)
 // two 256-B row gathers per edge (dS and P_recv, same row index), nothing else.
+// Returns the segment's share of d w_edge (before the s1 factor), the same value in every lane of the group.
 template <int SLOTS, bool NEG>
-__device__ __forceinline__ void edge_bwd_send_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
-                                                      const float esh, const float esc, const int u, const int beg, const int end) {
+__device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
+                                                        const float esh, const float esc, const int u, const int beg, const int end) {
     constexpr int G = 16 * SLOTS;
     const int gl = L.gl, gbase = L.gbase, slot = L.slot, ch = L.ch;
     const float4 psend = *(const float4*)(a.p_own + (size_t)u * EMB + ch);
@@ -251,9 +252,24 @@ __device__ __forceinline__ void edge_bwd_send_segment(const EdgeArgs& a, const f
         }
     }
     acc = slot_reduce<SLOTS>(acc); dw = slot_reduce<SLOTS>(dw);
-    if (slot == 0) {
-        *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
-        *(float4*)(a.dw_rows + (size_t)u * EMB + ch) = make_float4(s1 * dw.x, s1 * dw.y, s1 * dw.z, s1 * dw.w);
+    if (slot == 0) *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
+    return dw;
+}
+// d w_edge = s1 * sum over ALL edges of c_e * t_e.  Every lane group adds up the shares of the segments it serves (a fixed
+// assignment, hence a fixed order), the groups of a wave and the four waves of a block are combined in a fixed order and the
+// block stores ONE 64-float partial -- instead of a [n_send,64] matrix written here and column-summed by another kernel.
+template <int SLOTS>
+__device__ __forceinline__ void edge_dw_block_store(float4 dw, const float s1, float* __restrict__ dst, const int ch) {
+    __shared__ float4 red[4][16];
+    if (SLOTS <= 2) { dw.x += __shfl_xor(dw.x, 32); dw.y += __shfl_xor(dw.y, 32); dw.z += __shfl_xor(dw.z, 32); dw.w += __shfl_xor(dw.w, 32); }
+    if (SLOTS == 1) { dw.x += __shfl_xor(dw.x, 16); dw.y += __shfl_xor(dw.y, 16); dw.z += __shfl_xor(dw.z, 16); dw.w += __shfl_xor(dw.w, 16); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane < 16) red[wv][lane] = dw;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const float4 p0 = red[0][lane], p1 = red[1][lane], p2 = red[2][lane], p3 = red[3][lane];
+        *(float4*)(dst + ch) = make_float4(s1 * ((p0.x + p1.x) + (p2.x + p3.x)), s1 * ((p0.y + p1.y) + (p2.y + p3.y)),
+                                           s1 * ((p0.z + p1.z) + (p2.z + p3.z)), s1 * ((p0.w + p1.w) + (p2.w + p3.w)));
     }
 }
 template <int SLOTS, bool NEG>
@@ -264,13 +280,18 @@ __device__ __forceinline__ void edge_bwd_send_impl(const EdgeArgs& a, const floa
     const float esh = *a.e_shift, esc = *a.e_scale;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const int nwork = (a.n_own + RPW - 1) / RPW;
+    float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
         const int u = item * RPW + lane / G;
         if (u < a.n_own) {
             const int beg = a.seg_ptr[u], end = a.seg_ptr[u + 1];
-            if (end - beg <= edge_long_threshold(SLOTS)) edge_bwd_send_segment<SLOTS, NEG>(a, s1, L, w, esh, esc, u, beg, end);
+            if (end - beg <= edge_long_threshold(SLOTS)) {
+                const float4 dw = edge_bwd_send_segment<SLOTS, NEG>(a, s1, L, w, esh, esc, u, beg, end);
+                dwsum.x += dw.x; dwsum.y += dw.y; dwsum.z += dw.z; dwsum.w += dw.w;
+            }
         }
     }
+    edge_dw_block_store<SLOTS>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
 }
 template <int SLOTS>
 __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
@@ -282,8 +303,11 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send_long(EdgeArgs a, int thre
     const EdgeLane<4> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    if (s1 < 0.f) edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { edge_bwd_send_segment<4, true>(a, s1, L, w, esh, esc, u, beg, end); });
-    else edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { edge_bwd_send_segment<4, false>(a, s1, L, w, esh, esc, u, beg, end); });
+    float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4 dw) { dwsum.x += dw.x; dwsum.y += dw.y; dwsum.z += dw.z; dwsum.w += dw.w; };
+    if (s1 < 0.f) edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { add(edge_bwd_send_segment<4, true>(a, s1, L, w, esh, esc, u, beg, end)); });
+    else edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { add(edge_bwd_send_segment<4, false>(a, s1, L, w, esh, esc, u, beg, end)); });
+    edge_dw_block_store<4>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -63,26 +63,24 @@ __device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b, flo
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 24
 #define WG_STEPS 4   // 4-row MFMA steps per batch of loads
-struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float* d2; int n; int blk0; int slab0; };
+struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; int n; int blk0; int slab0; };
 struct WgArgs { int njobs; int nblocks; int rows_per_wave; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
-struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS], e[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
+struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
 
-// EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f), 2 = column sum of a second matrix
-// (Q -> d w_edge)
+// EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f)
 template <int EXTRA>
 __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int col) {
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) {
         const int r = row0 + 4 * s + g;
-        t.x[s] = t.d[s] = t.e[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        t.x[s] = t.d[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         t.p0[s] = t.p1[s] = 0;
         if (r < rend) {
             t.x[s] = *(const float4*)(jb.x + (size_t)r * EMB + col);
             t.d[s] = *(const float4*)(jb.d + (size_t)r * EMB + col);
             if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
-            if (EXTRA == 2) t.e[s] = *(const float4*)(jb.d2 + (size_t)r * EMB + col);
         }
     }
 }
@@ -112,7 +110,6 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
                 const float deg = (float)(cur.p1[s] - cur.p0[s]);
                 ce.x = fmaf(deg, db[0], ce.x); ce.y = fmaf(deg, db[1], ce.y); ce.z = fmaf(deg, db[2], ce.z); ce.w = fmaf(deg, db[3], ce.w);
             }
-            if (EXTRA == 2) { ce.x += cur.e[s].x; ce.y += cur.e[s].y; ce.z += cur.e[s].z; ce.w += cur.e[s].w; }
         }
         cur = nxt;
     }
@@ -134,23 +131,51 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
     }
 }
 
-__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e) {
+// d w_edge: the edge-gradient passes leave one 64-float partial per thread block (up to thousands).  Third block type of
+// this launch: block j of convolution c adds DW_CHUNK consecutive partial rows in a fixed order, so that k_reduce is left
+// with a few dozen rows per convolution like for every other gradient.
+#define DW_CHUNK 128
+struct DwRedArgs { const float* src[3]; float* dst[3]; int nparts[3]; int blk0[4]; };
+__device__ __forceinline__ void dw_reduce_block(const DwRedArgs& d, int b, float* red) {
+    int c = 0;
+    while (c < 2 && b >= d.blk0[c + 1]) ++c;
+    const int chunk = b - d.blk0[c], col = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int p0 = chunk * DW_CHUNK, p1 = min(d.nparts[c], p0 + DW_CHUNK);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* src = d.src[c] + col;
+    int p = p0 + part;
+    for (; p + 12 < p1; p += 16) {   // 4 loads in flight per thread; the order of the adds is fixed
+        const float v0 = src[(size_t)p * EMB], v1 = src[(size_t)(p + 4) * EMB], v2 = src[(size_t)(p + 8) * EMB], v3 = src[(size_t)(p + 12) * EMB];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; p < p1; p += 4) s0 += src[(size_t)p * EMB];
+    red[part * EMB + col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part == 0) d.dst[c][(size_t)chunk * EMB + col] = (red[col] + red[EMB + col]) + (red[2 * EMB + col] + red[3 * EMB + col]);
+}
+
+__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e, DwRedArgs dw) {
     extern __shared__ __attribute__((aligned(16))) float wg_red[];   // [WG_WAVES][WG_SLAB]
-    if ((int)blockIdx.x >= a.nblocks) {   // the (short) first-embedding-layer chunks come after the long MFMA chunks
-        embed1_wgrad_block(e, blockIdx.x - a.nblocks, wg_red);
+    const int ndw = dw.blk0[3];
+    if ((int)blockIdx.x < ndw) {   // the d w_edge pre-reduction first: a few short blocks, out of the way before the long chunks fill the chip
+        dw_reduce_block(dw, blockIdx.x, wg_red);
+        return;
+    }
+    const int bx = (int)blockIdx.x - ndw;
+    if (bx >= a.nblocks) {   // the (short) first-embedding-layer chunks come after the long MFMA chunks (measured: first is worse)
+        embed1_wgrad_block(e, bx - a.nblocks, wg_red);
         return;
     }
     int ji = 0;   // last job whose first block is <= this block: binary search (a linear scan is one dependent scalar load per job)
     for (int hi = a.njobs; hi - ji > 1;) {
         const int mid = (ji + hi) >> 1;
-        if ((int)blockIdx.x >= a.job[mid].blk0) ji = mid; else hi = mid;
+        if (bx >= a.job[mid].blk0) ji = mid; else hi = mid;
     }
     const WgJob jb = a.job[ji];
-    const int lb = blockIdx.x - jb.blk0, wv = threadIdx.x >> 6;
+    const int lb = bx - jb.blk0, wv = threadIdx.x >> 6;
     const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * a.rows_per_wave), rend = min(jb.n, rbeg + a.rows_per_wave);   // may be empty: zeros
     float* mine = wg_red + wv * WG_SLAB;
     if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);
-    else if (jb.d2) wg_body<2>(jb, mine, rbeg, rend);
     else wg_body<0>(jb, mine, rbeg, rend);
     __syncthreads();
     float4* slab = (float4*)(a.partial + (size_t)(jb.slab0 + lb) * WG_SLAB);

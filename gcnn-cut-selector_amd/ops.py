@@ -82,13 +82,15 @@ def conv_edge_bwd(graph: BipartiteGraph, recv_is_left: bool, nrows, pl, pr, w_ed
         sptr, soth, scoef, n_send = _edge_side(graph, not recv_is_left)
         p_send, p_recv = (pr, pl) if recv_is_left else (pl, pr)
         d_send = torch.empty((n_send, EMB), dtype=torch.float32, device=dev)
-        rows = torch.zeros((max(n_send, 1), EMB), dtype=torch.float32, device=dev)  # per-sender shares of d w_edge
+        rows = torch.empty((4096, EMB), dtype=torch.float32, device=dev)  # per-block partials of d w_edge (GCNN_EDGE_DW_PARTS)
+        n_parts = C.c_int32(0)
         _lib.check(lib.gcnn_conv_edge_bwd_send(_ptr(sptr), _ptr(soth), _ptr(scoef), n_send, graph.n_edges, _ptr(p_send),
                                                _ptr(p_recv), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale), _ptr(s1), _ptr(d_s),
-                                               _ptr(d_send), _ptr(rows), graph.v_max_deg if recv_is_left else graph.l_max_deg,
-                                               _stream(dev)), "gcnn_conv_edge_bwd_send")
+                                               _ptr(d_send), _ptr(rows), C.byref(n_parts),
+                                               graph.v_max_deg if recv_is_left else graph.l_max_deg, _stream(dev)),
+                   "gcnn_conv_edge_bwd_send")
     d_pl, d_pr = (d_recv, d_send) if recv_is_left else (d_send, d_recv)
-    return d_pl, d_pr, rows.sum(0)
+    return d_pl, d_pr, rows[:n_parts.value].sum(0)
 
 
 class SegmentPlan:

@@ -126,8 +126,10 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  * bwd_send: segments grouped by the SENDING node u; the ReLU pattern is recomputed from the two projected tables with the
  *           forward's own expression (bit-identical): with r = oth[e], J_e = (c_e*w_edge + p_send[u]) + p_recv[r] and
  *           t_e = [s1*J_e > 0] * d_s[r]:
- *           d_p_send[u] = s1*sum_{e in seg(u)} t_e ;  dw_rows[u] = s1*sum_{e in seg(u)} c_e*t_e  (its column sum is the
- *           gradient of feature_module_edge's kernel, model.py:490-492). */
+ *           d_p_send[u] = s1*sum_{e in seg(u)} t_e ;  the gradient of feature_module_edge's kernel (model.py:490-492),
+ *           s1*sum_e c_e*t_e, is left as *n_parts partial rows dw_partial[i][64] (one per thread block, fixed summation
+ *           order; the caller adds the rows up).  dw_partial must hold GCNN_EDGE_DW_PARTS rows. */
+#define GCNN_EDGE_DW_PARTS 4096
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
                        const float* e_scale, const float* s1, float* s_out, float* n_rows /* optional */,
@@ -136,8 +138,8 @@ int gcnn_conv_edge_bwd_recv(const float* d_s, const float* n_rows, const float* 
                             void* stream);
 int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_send, int32_t n_edges,
                             const float* p_send, const float* p_recv, const float* w_edge, const float* e_shift,
-                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_rows,
-                            int32_t max_degree /* longest segment, 0 = unknown */, void* stream);
+                            const float* e_scale, const float* s1, const float* d_s, float* d_p_send, float* dw_partial,
+                            int32_t* n_parts /* host */, int32_t max_degree /* longest segment, 0 = unknown */, void* stream);
 
 /* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
  * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied

@@ -36,14 +36,14 @@ int main() {
         WgArgs a; a.njobs = c.njobs; a.partial = partial; a.rows_per_wave = WG_ROWS; int blk = 0;
         for (int j = 0; j < c.njobs; ++j) {
             a.job[j] = WgJob{x + (size_t)j * NMAX * 64, j == 1 ? sx : nullptr, d + (size_t)j * NMAX * 64, c.extra[j] == 1 ? seg : nullptr,
-                             c.extra[j] == 2 ? q : nullptr, c.n[j], blk, blk};
+                             c.n[j], blk, blk};
             blk += cdiv(c.n[j], WG_ROWS * WG_WAVES);
         }
         a.nblocks = blk;
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{});
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{}, DwRedArgs{});
         CK(hipEventRecord(e0, 0));
         const int R = 50;
-        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{});
+        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{}, DwRedArgs{});
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-20s blocks %4d  %.2f us/launch\n", c.name, blk, ms * 1000 / R);
