@@ -469,13 +469,23 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
     }
     // fewer than 256 blocks of this size: spread the tiles over all CUs instead (fewer tiles per block, idle waves are free)
     const bool spread = sum_want < 256 && total > 1024;
-    blk0[0] = 0;
+    int nb[3];
     for (int i = 0; i < ngroups; ++i) {
-        int nb = want[i];
-        if ((sum_want > 256 || spread) && nb > 0)
-            nb = std::max(1, std::min(spread ? ntile[i] : want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
-        blk0[i + 1] = blk0[i] + nb;
+        nb[i] = want[i];
+        if ((sum_want > 256 || spread) && nb[i] > 0)
+            nb[i] = std::max(1, std::min(spread ? ntile[i] : want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
     }
+    // rounding each share up can leave 257 or 258 blocks for 256 CUs, and a block of a one-block-per-CU launch that has to wait
+    // for a free CU adds its whole run time to the launch: take the excess from the largest group
+    if (sum_want > 256 || spread)
+        for (int total = nb[0] + (ngroups > 1 ? nb[1] : 0) + (ngroups > 2 ? nb[2] : 0); total > 256; --total) {
+            int big = 0;
+            for (int i = 1; i < ngroups; ++i) if (nb[i] > nb[big]) big = i;
+            if (nb[big] <= 1) break;
+            --nb[big];
+        }
+    blk0[0] = 0;
+    for (int i = 0; i < ngroups; ++i) blk0[i + 1] = blk0[i] + nb[i];
     return nwaves;
 }
 #define ROWS_LAUNCH(NAME, KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ...)                                                \
