@@ -82,7 +82,7 @@ def conv_edge_bwd(graph: BipartiteGraph, recv_is_left: bool, nrows, pl, pr, w_ed
         sptr, soth, scoef, n_send = _edge_side(graph, not recv_is_left)
         p_send, p_recv = (pr, pl) if recv_is_left else (pl, pr)
         d_send = torch.empty((n_send, EMB), dtype=torch.float32, device=dev)
-        rows = torch.empty((4096, EMB), dtype=torch.float32, device=dev)  # per-block partials of d w_edge (GCNN_EDGE_DW_PARTS)
+        rows = torch.empty((16384, EMB), dtype=torch.float32, device=dev)  # per-block partials of d w_edge (GCNN_EDGE_DW_PARTS)
         n_parts = C.c_int32(0)
         _lib.check(lib.gcnn_conv_edge_bwd_send(_ptr(sptr), _ptr(soth), _ptr(scoef), n_send, graph.n_edges, _ptr(p_send),
                                                _ptr(p_recv), _ptr(w_edge), _ptr(e_shift), _ptr(e_scale), _ptr(s1), _ptr(d_s),

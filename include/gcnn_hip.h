@@ -129,7 +129,7 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  *           d_p_send[u] = s1*sum_{e in seg(u)} t_e ;  the gradient of feature_module_edge's kernel (model.py:490-492),
  *           s1*sum_e c_e*t_e, is left as *n_parts partial rows dw_partial[i][64] (one per thread block, fixed summation
  *           order; the caller adds the rows up).  dw_partial must hold GCNN_EDGE_DW_PARTS rows. */
-#define GCNN_EDGE_DW_PARTS 4096
+#define GCNN_EDGE_DW_PARTS 16384
 int gcnn_conv_edge_fwd(const int32_t* seg_ptr, const int32_t* oth, const float* coef, int32_t n_recv, int32_t n_edges,
                        const float* p_recv, const float* p_oth, const float* w_edge, const float* e_shift,
                        const float* e_scale, const float* s1, float* s_out, float* n_rows /* optional */,
