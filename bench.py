@@ -241,6 +241,11 @@ def main():
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     group = None
+    # RCCL prints a version banner to STDOUT when its communicator comes up; the contract is ONE JSON line on stdout, so
+    # everything before that line goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 or os.environ.get("GCNN_FORCE_DP") == "1":  # GCNN_FORCE_DP: rehearse the collective path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -362,7 +367,10 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.problem, args.batch, 0)
         out["config"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["best_value"], 1)   # against the fastest CPU point
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     if group is not None:
         dist.destroy_process_group()
 
