@@ -538,9 +538,18 @@ static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, 
         LAUNCHCHK();
     }
     if (blk0[1] == 0) return 0;
-    if (tail == CF_LOSS) ROWS_LAUNCH("k_conv_fwd<loss>", (k_conv_fwd<8, CF_LOSS>), (k_conv_fwd<4, CF_LOSS>), nwaves, blk0[1], smem, st, a);
-    else if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout>", (k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
+    if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout>", (k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
     else ROWS_LAUNCH("k_conv_fwd<proj>", (k_conv_fwd<8, CF_PROJ>), (k_conv_fwd<4, CF_PROJ>), nwaves, blk0[1], smem, st, a);
+    return 0;
+}
+// training turnaround: the last forward program and the first backward program of the cut rows in one launch (k_rows.hpp)
+static int launch_conv_turn(const ConvFArgs& a, const ConvBArgs& b, hipStream_t st) {
+    int blk0[2];
+    const int ns = 10;
+    const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
+    if (blk0[1] == 0) return 0;
+    ROWS_LAUNCH("k_conv_turn (readout + loss head + cut-row gradients)", k_conv_turn<8>, k_conv_turn<4>, nwaves, blk0[1],
+                ROWS_LDS_FLOATS(5, 5) * sizeof(float), st, a, b);
     return 0;
 }
 static int launch_conv_bwd(ConvBGroupArgs& m, hipStream_t st) {
@@ -582,6 +591,7 @@ static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
 // edge pass + the receiver-side update program S -> A -> Z1 -> X' (model.py:498-508, 568-573) and, in the same launch, what
 // consumes X': the next convolution's projection (wt, bt -> t_out) or the readout
 struct LossHead { const float* targets; float scale; float* g_o1; float* partial; };   // CF_LOSS extras
+static ConvBArgs conv_bwd_args(const float* p, const ConvIO& c, const float* in, const float* w0);
 static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, const float* wt, const float* bt,
                         float* t_out, int tail, float* scores, const LossHead* head, const IplanArgs* plan = nullptr) {
     int rc;
@@ -597,7 +607,10 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
     a.w2 = p + poff(c.pbase + C_W2); a.b2 = p + poff(c.pbase + C_B2); a.out = c.OUT;
     a.wt = wt; a.bt = bt; a.t_out = t_out;
     if (tail != CF_PROJ) { a.ws = p + poff(P_OUT + 2); a.bs = p + poff(P_OUT + 3); a.scores = scores; }
-    if (tail == CF_LOSS) { a.targets = head->targets; a.loss_scale = head->scale; a.g_o1 = head->g_o1; a.head_partial = head->partial; }
+    if (tail == CF_LOSS) {   // training: the cut rows turn around in this launch (their receiver gradients land in the workspace)
+        a.targets = head->targets; a.loss_scale = head->scale; a.g_o1 = head->g_o1; a.head_partial = head->partial;
+        return launch_conv_turn(a, conv_bwd_args(p, c, head->g_o1, wt), st);
+    }
     return launch_conv_fwd(a, tail, plan, st);
 }
 
@@ -746,27 +759,52 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
 
 
 // ---- backward ---------------------------------------------------------------------------------------------------
+struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; };
 struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
     DwRedArgs dw; int ndw;   // d w_edge pre-reductions (one per convolution with edge-gradient partials)
+    PendWg pend[WG_MAX_JOBS]; int npend;   // weight-gradient jobs as collected; ordered and placed by place_wg
 };
 static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr,
-                   int n, float* gw, float* gb, float* g2, float* partial) {
+                   int n, float* gw, float* gb, float* g2, float* /*partial*/) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
-    WgJob& j = jl.wg.job[jl.wg.njobs++];
-    const int nb = cdiv(n, jl.wg.rows_per_wave * WG_WAVES);   // blocks = slabs: four chunks each
-    j.x = x; j.sx = sx; j.d = dmat; j.seg_ptr = seg_ptr; j.n = n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
-    const float* src = partial + (size_t)jl.nslab * WG_SLAB;
-    jl.wg.nblocks += nb; jl.nslab += nb;
-    auto rd = [&](const float* s, float* dst, int len) {
-        RdJob& r = jl.rd.job[jl.rd.njobs++];
-        r.src = s; r.dst = dst; r.nparts = nb; r.stride = WG_SLAB; r.len = len; r.blk0 = jl.rdblk;
-        jl.rdblk += cdiv(len, EMB);
-    };
-    rd(src, gw, EMB * EMB);
-    if (gb) rd(src + EMB * EMB, gb, EMB);
-    if (g2) rd(src + EMB * EMB + EMB, g2, EMB);
+    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2};
+}
+// Order the collected jobs and give them their block ranges.  Several jobs read the same matrix (dZ1 feeds the gradients of
+// both halves of W1; a raw embedding X is the operand of up to three products): such jobs are placed next to each other,
+// and every job starts at a block index that is a multiple of 8, so the blocks of two adjacent jobs that read the same rows
+// run on the same XCD (blocks are dealt to the eight XCDs round-robin) at about the same time -- the second read hits that
+// XCD's L2 instead of going to memory.  Padding blocks own no rows and exit at once.  Values do not depend on the order.
+static void place_wg(JobList& jl, float* partial) {
+    bool used[WG_MAX_JOBS] = {};
+    int order[WG_MAX_JOBS], last = -1;
+    for (int k = 0; k < jl.npend; ++k) {
+        int pick = -1;
+        if (last >= 0)
+            for (int i = 0; i < jl.npend && pick < 0; ++i)
+                if (!used[i] && jl.pend[i].n == jl.pend[last].n && (jl.pend[i].x == jl.pend[last].x || jl.pend[i].d == jl.pend[last].d)) pick = i;
+        for (int i = 0; i < jl.npend && pick < 0; ++i)   // otherwise the longest job not yet placed (ties: collection order)
+            if (!used[i]) { pick = i; for (int q = i + 1; q < jl.npend; ++q) if (!used[q] && jl.pend[q].n > jl.pend[pick].n) pick = q; }
+        used[pick] = true; order[k] = last = pick;
+    }
+    for (int k = 0; k < jl.npend; ++k) {
+        const PendWg& q = jl.pend[order[k]];
+        WgJob& j = jl.wg.job[jl.wg.njobs++];
+        const int nb = cdiv(q.n, jl.wg.rows_per_wave * WG_WAVES);   // blocks = slabs: four chunks each
+        j.x = q.x; j.sx = q.sx; j.d = q.d; j.seg_ptr = q.seg_ptr; j.n = q.n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
+        const float* src = partial + (size_t)jl.nslab * WG_SLAB;
+        jl.wg.nblocks += (nb + 7) & ~7; jl.nslab += nb;
+        auto rd = [&](const float* s, float* dst, int len) {
+            RdJob& r = jl.rd.job[jl.rd.njobs++];
+            r.src = s; r.dst = dst; r.nparts = nb; r.stride = WG_SLAB; r.len = len; r.blk0 = jl.rdblk;
+            jl.rdblk += cdiv(len, EMB);
+        };
+        rd(src, q.gw, EMB * EMB);
+        if (q.gb) rd(src + EMB * EMB, q.gb, EMB);
+        if (q.g2) rd(src + EMB * EMB + EMB, q.g2, EMB);
+    }
+    jl.npend = 0;
 }
 static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int stride, int len) {
     if (nparts <= 0) return;
@@ -886,7 +924,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         t.in_a = in_a; t.wa = wa; t.in_b = in_b; t.wb = wb; t.add = gx; t.x = x; t.g_x = gx; t.w2 = p + poff(pb + E_W2);
         t.g_e1 = ge1; t.n = n;
     };
-    {   // cut rows: readout -> conv v->k receiver gradients
+    if (!fused_head) {   // cut rows: readout -> conv v->k receiver gradients (fused head: gcnn_forward_loss's last launch did it)
         ConvBGroupArgs m; memset(&m, 0, sizeof(m));
         m.cb = conv_bwd_args(p, cv[2], G.O1, p + poff(P_OUT));
         if ((rc = launch_conv_bwd(m, st))) return rc;
@@ -929,6 +967,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     }
     for (int i = 0; i < 3; ++i)
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
+    place_wg(jl, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
     for (int k = jl.ndw; k < 3; ++k) jl.dw.blk0[k + 1] = jl.dw.blk0[k];
     if (jl.wg.nblocks + ea.nblocks + jl.dw.blk0[3] > 0) {

@@ -56,26 +56,36 @@ __device__ __forceinline__ void rt_store(const RTile& t, float* x, int row, bool
 }
 
 // acc[mo] += Wop[16*mo + (lane&15)][kf] * (scale * T[kf]), kf = 16*mt + 4*g + i;
-// forward (x @ W): Wop[o][k] = W[k][o];  backward (x @ W^T): Wop[o][k] = W[o][k].  wl: the matrix in LDS, row stride LDW.
-template <bool TRANSB>
+// forward (x @ W): Wop[o][k] = W[k][o];  backward (x @ W^T): Wop[o][k] = W[o][k].  wl: the matrix in LDS.
+// MODE (a bool converts): GEMM_FWD  = forward, matrix staged k-interleaved (stage_lds<..., true>): one float4 per four MFMAs
+//                         GEMM_BWD  = backward, matrix staged row-major [64][LDW]: one float4 per four MFMAs
+//                         GEMM_FWD_RM = forward from the ROW-MAJOR staging (four scalar reads per four MFMAs): for a program that
+//                                     needs a matrix in both directions and has no LDS for two copies (convturn_program)
+enum { GEMM_FWD = 0, GEMM_BWD = 1, GEMM_FWD_RM = 2 };
+template <int MODE>
 __device__ __forceinline__ void rt_gemm(const RTile& t, float scale, const float* wl, f32x4 (&acc)[4], int lane) {
     const int m = lane & 15, g = lane >> 4;
     wl = lds_here(wl);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float av[4][4];  // [mo][i]
-        if (TRANSB) {
+        if (MODE == GEMM_BWD) {
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo) {
                 const float4 w4 = *(const float4*)(wl + (16 * mo + m) * LDW + 16 * mt + 4 * g);
                 av[mo][0] = w4.x; av[mo][1] = w4.y; av[mo][2] = w4.z; av[mo][3] = w4.w;
             }
-        } else {   // forward matrices are staged k-interleaved (stage_lds<..., true>): W[4q..4q+3][o] are four consecutive floats
+        } else if (MODE == GEMM_FWD) {   // W[4q..4q+3][o] are four consecutive floats
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo) {
                 const float4 w4 = *(const float4*)(wl + ((4 * mt + g) * 64 + 16 * mo + m) * 4);
                 av[mo][0] = w4.x; av[mo][1] = w4.y; av[mo][2] = w4.z; av[mo][3] = w4.w;
             }
+        } else {
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[mo][i] = wl[(16 * mt + 4 * g + i) * LDW + 16 * mo + m];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -86,7 +96,7 @@ __device__ __forceinline__ void rt_gemm(const RTile& t, float scale, const float
     }
 }
 // o = (scale * in) x W
-template <bool TRANSB>
+template <int TRANSB>
 __device__ __forceinline__ void rt_mm(RTile& o, const RTile& in, float scale, const float* wl, int lane) {
     f32x4 acc[4];
 #pragma unroll
@@ -98,7 +108,7 @@ __device__ __forceinline__ void rt_mm(RTile& o, const RTile& in, float scale, co
         for (int i = 0; i < 4; ++i) o.v[mo][i] = acc[mo][i];
 }
 // o = (sa * a) x Wa + b x Wb   (same accumulators, a first)
-template <bool TRANSB>
+template <int TRANSB>
 __device__ __forceinline__ void rt_mm2(RTile& o, const RTile& a, float sa, const float* wa, const RTile& b, const float* wb, int lane) {
     f32x4 acc[4];
 #pragma unroll
@@ -302,6 +312,41 @@ __device__ __forceinline__ float row_sum16(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));  // row_ror:8
     return x;
 }
+// score = O1 . ws + bs (model.py:208) for the tile's 16 rows (every lane of a row's four lane groups gets the row's score)
+__device__ __forceinline__ float readout_score(const RTile& o1, const float* ws_lds, float bs, int g) {
+    float sum = 0.f;
+    const float* wsv = lds_here(ws_lds);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4 w = *(const float4*)(wsv + 16 * m + 4 * g);
+        sum = fmaf(o1.v[m][0], w.x, fmaf(o1.v[m][1], w.y, fmaf(o1.v[m][2], w.z, fmaf(o1.v[m][3], w.w, sum))));
+    }
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    return sum + bs;
+}
+// the MSE head of one tile (CF_LOSS above): go = dO1pre, and the tile's partial slab {dws, dbs, loss}
+__device__ __forceinline__ void loss_head_tile(RTile& go, const RTile& o1, float score, const ConvFArgs& a, const float* ws_lds,
+                                               int tile, int row, bool ok, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const float dlt = ok ? score - a.targets[row] : 0.f;
+    const float ds = 2.f * dlt * a.loss_scale;
+    const float* wsv = lds_here(ws_lds);
+    float* slab = a.head_partial + (size_t)tile * HEAD_SLAB;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4 w = *(const float4*)(wsv + 16 * m + 4 * g);
+        const float wv4[4] = {w.x, w.y, w.z, w.w};
+        float cs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            go.v[m][i] = o1.v[m][i] > 0.f ? ds * wv4[i] : 0.f;
+            cs[i] = row_sum16(ds * o1.v[m][i]);
+        }
+        if (j == 0) *(float4*)(slab + 16 * m + 4 * g) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    }
+    const float dbs = row_sum16(ds), ls = row_sum16(a.loss_scale * dlt * dlt);
+    if (lane == 0) { slab[EMB] = dbs; slab[EMB + 1] = ls; }
+}
 template <int TAIL, int NT>
 __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, int bid, int nblk) {
     constexpr int NWAVES = NT / 64, NM = 5, NV = 5;   // Wf W1a W1b W2 Wt | bf b1 b2 bt ws
@@ -361,36 +406,12 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
             rt_bias<true>(t1, vecs + 3 * 64, g);
             rt_clear_unless(t1, ok);
             rt_store(t1, a.t_out, row, ok, g);
-            float sum = 0.f;
-            const float* wsv = lds_here(vecs + 4 * 64);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 w = *(const float4*)(wsv + 16 * m + 4 * g);
-                sum = fmaf(t1.v[m][0], w.x, fmaf(t1.v[m][1], w.y, fmaf(t1.v[m][2], w.z, fmaf(t1.v[m][3], w.w, sum))));
-            }
-            sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-            const float score = sum + bs;
+            const float score = readout_score(t1, vecs + 4 * 64, bs, g);
             if (g == 0 && ok) a.scores[row] = score;
             if (TAIL == CF_LOSS) {
-                const float dlt = ok ? score - a.targets[row] : 0.f;
-                const float ds = 2.f * dlt * a.loss_scale;
                 RTile go;
-                float* slab = a.head_partial + (size_t)tile * HEAD_SLAB;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float4 w = *(const float4*)(wsv + 16 * m + 4 * g);
-                    const float wv4[4] = {w.x, w.y, w.z, w.w};
-                    float cs[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        go.v[m][i] = t1.v[m][i] > 0.f ? ds * wv4[i] : 0.f;
-                        cs[i] = row_sum16(ds * t1.v[m][i]);
-                    }
-                    if (j == 0) *(float4*)(slab + 16 * m + 4 * g) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-                }
+                loss_head_tile(go, t1, score, a, vecs + 4 * 64, tile, row, ok, lane);
                 rt_store(go, a.g_o1, row, ok, g);
-                const float dbs = row_sum16(ds), ls = row_sum16(a.loss_scale * dlt * dlt);
-                if (lane == 0) { slab[EMB] = dbs; slab[EMB + 1] = ls; }
             }
         }
         cur = nxt;
@@ -473,6 +494,108 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
         rt_store(t1, a.g_precv, row, ok, g);
         cur = nxt;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Program 2+3 (training turnaround): the LAST forward program (cut rows: receiver update of conv v->k, readout, MSE head)
+// and the FIRST backward program (the same rows' receiver gradient, entered through the readout's Dense(64,relu)) are both
+// row-local on the same tiles with nothing between them, so a training step runs them as ONE program: the activations the
+// backward half masks with (X', Z1, O1) and its input gradient dO1pre never leave the registers, and the step has one launch
+// (and one weight staging) less.  Every tensor the weight-gradient launch or the edge passes read is still stored.
+// The five matrices serve both directions, so they are staged once, row-major: the forward products read them with
+// rt_gemm<GEMM_FWD_RM>, the backward products as float4 (two stagings would not fit the LDS).
+//   f: as convf_program<CF_LOSS>;  b: as convb_program with in = f.g_o1, w0 = f.wt, x_out = f.out, z1 = f.z1 (not re-read)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void convturn_program(const ConvFArgs& a, const ConvBArgs& b, float* smem, int bid, int nblk) {
+    constexpr int NWAVES = NT / 64, NM = 5;   // Wf W1a W1b W2 Wt | bf b1 b2 bt ws
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int ntile = (a.n + 15) >> 4;
+    float* vecs = smem + NM * 64 * LDW;
+    int tile = bid + nblk * wv;
+    struct Ops { RTile s_in, xr, nr; int seg0, seg1; } cur, nxt;
+    auto load_ops = [&](Ops& d, int t) {
+        const int row = t * 16 + j;
+        const bool ok = row < a.n;
+        rt_load(d.s_in, a.s, row, ok, g);
+        rt_load(d.xr, a.xrecv, row, ok, g);
+        rt_load(d.nr, b.nrows, row, ok, g);
+        d.seg0 = ok ? a.seg_ptr[row] : 0; d.seg1 = ok ? a.seg_ptr[row + 1] : 0;
+    };
+    load_ops(cur, tile);
+    {
+        const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
+        const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, a.ws};
+        stage_lds<5, 5, NT>(smem, w, v);
+    }
+    const float s2 = *a.s2, s1 = *b.s1, bs = *a.bs;
+    float* const WF = smem; float* const W1A = smem + 64 * LDW; float* const W1B = smem + 2 * 64 * LDW;
+    float* const W2 = smem + 3 * 64 * LDW; float* const WT = smem + 4 * 64 * LDW;
+    __syncthreads();
+    for (; tile < ntile; tile += nblk * NWAVES) {
+        load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
+        const int row = tile * 16 + j;
+        const bool ok = row < a.n;
+        RTile t0, z1, xo, t1;
+        // ---- forward half (convf_program<CF_LOSS>)
+        rt_mm<GEMM_FWD_RM>(t0, cur.s_in, 1.f, WF, lane);
+        {   // + deg * bf
+            const float deg = (float)(cur.seg1 - cur.seg0);
+            const float* bfv = lds_here(vecs);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 bb = *(const float4*)(bfv + 16 * m + 4 * g);
+                t0.v[m][0] = fmaf(deg, bb.x, t0.v[m][0]); t0.v[m][1] = fmaf(deg, bb.y, t0.v[m][1]);
+                t0.v[m][2] = fmaf(deg, bb.z, t0.v[m][2]); t0.v[m][3] = fmaf(deg, bb.w, t0.v[m][3]);
+            }
+        }
+        rt_clear_unless(t0, ok);
+        rt_store(t0, a.a_out, row, ok, g);
+        rt_mm2<GEMM_FWD_RM>(z1, t0, s2, W1A, cur.xr, W1B, lane);
+        rt_bias<true>(z1, vecs + 64, g);
+        rt_clear_unless(z1, ok);
+        rt_store(z1, a.z1, row, ok, g);
+        rt_mm<GEMM_FWD_RM>(xo, z1, 1.f, W2, lane);
+        rt_bias<true>(xo, vecs + 2 * 64, g);
+        rt_clear_unless(xo, ok);
+        rt_store(xo, a.out, row, ok, g);
+        rt_mm<GEMM_FWD_RM>(t1, xo, 1.f, WT, lane);
+        rt_bias<true>(t1, vecs + 3 * 64, g);
+        rt_clear_unless(t1, ok);
+        rt_store(t1, a.t_out, row, ok, g);
+        const float score = readout_score(t1, vecs + 4 * 64, bs, g);
+        if (g == 0 && ok) a.scores[row] = score;
+        loss_head_tile(t0, t1, score, a, vecs + 4 * 64, tile, row, ok, lane);   // t0 = dO1pre
+        rt_store(t0, a.g_o1, row, ok, g);
+        // ---- backward half (convb_program)
+        rt_mm<GEMM_BWD>(t1, t0, 1.f, WT, lane);
+        rt_mask(t1, xo);
+        rt_store(t1, b.g_out, row, ok, g);
+        rt_mm<GEMM_BWD>(t0, t1, 1.f, W2, lane);
+        rt_mask(t0, z1);
+        rt_store(t0, b.g_z1, row, ok, g);
+        rt_mm<GEMM_BWD>(t1, t0, 1.f, W1B, lane);
+        rt_store(t1, b.g_xrecv, row, ok, g);
+        rt_mm<GEMM_BWD>(t1, t0, 1.f, W1A, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t1.v[m][i] *= s2;
+        rt_store(t1, b.g_a, row, ok, g);
+        rt_mm<GEMM_BWD>(t0, t1, 1.f, WF, lane);
+        rt_store(t0, b.g_s, row, ok, g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t0.v[m][i] = s1 * t0.v[m][i] * cur.nr.v[m][i];
+        rt_store(t0, b.g_precv, row, ok, g);
+        cur = nxt;
+    }
+}
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void k_conv_turn(ConvFArgs f, ConvBArgs b) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    convturn_program<NWAVES * 64>(f, b, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

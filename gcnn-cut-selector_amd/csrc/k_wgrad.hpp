@@ -77,7 +77,11 @@ __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, i
         const int r = row0 + 4 * s + g;
         t.x[s] = t.d[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         t.p0[s] = t.p1[s] = 0;
+#ifdef WG_ABL_NOLOAD
+        if (r < rend && row0 < 0) {
+#else
         if (r < rend) {
+#endif
             t.x[s] = *(const float4*)(jb.x + (size_t)r * EMB + col);
             t.d[s] = *(const float4*)(jb.d + (size_t)r * EMB + col);
             if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
@@ -104,7 +108,11 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
             for (int va = 0; va < 4; ++va)
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb)
+#ifdef WG_ABL_NOMFMA
+                    acc[va][vb][0] += xa[va] * db[vb];
+#else
                     acc[va][vb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[va], db[vb], acc[va][vb], 0, 0, 0);
+#endif
             cs.x += db[0]; cs.y += db[1]; cs.z += db[2]; cs.w += db[3];
             if (EXTRA == 1) {
                 const float deg = (float)(cur.p1[s] - cur.p0[s]);
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e, D
     }
     const WgJob jb = a.job[ji];
     const int lb = bx - jb.blk0, wv = threadIdx.x >> 6;
+    if ((long long)lb * WG_WAVES * a.rows_per_wave >= jb.n) return;   // padding block (jobs start at multiples of 8 blocks): owns no rows, no slab
     const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * a.rows_per_wave), rend = min(jb.n, rbeg + a.rows_per_wave);   // may be empty: zeros
     float* mine = wg_red + wv * WG_SLAB;
     if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);

@@ -96,15 +96,15 @@ int main() {
         // send pass: owner = the other side; gathers dS and P_recv rows of the forward's receivers
         EdgeArgs b; memset(&b, 0, sizeof(b));
         b.seg_ptr = dir ? dl_ptr : dv_ptr; b.oth = dir ? dl_oth : dv_oth; b.coef = dcoef; b.w_edge = par; b.e_shift = par + 64; b.e_scale = par + 65; b.s1 = par + 66;
-        b.d_s = PL; b.p_own = dir ? PL : PR; b.p_oth = dir ? PR : PL; b.out = S; b.dw_rows = Q; b.n_own = dir ? NL : NV;
+        b.d_s = PL; b.p_own = dir ? PL : PR; b.p_oth = dir ? PR : PL; b.out = S; b.dw_partial = Q; b.n_own = dir ? NL : NV;
         const int gridb = std::min(cdiv(b.n_own, 4), 2048), gridb2 = std::min(cdiv(cdiv(b.n_own, 2), 4), 2048);
         snprintf(nm, 64, "bwd_send dir=%d slots=4 (recompute)", dir); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_bwd_send<4>), dim3(gridb), dim3(256), 0, 0, b); });
         snprintf(nm, 64, "bwd_send dir=%d slots=2 (recompute)", dir); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_bwd_send<2>), dim3(gridb2), dim3(256), 0, 0, b); });
         snprintf(nm, 64, "bwd_send dir=%d slots=1 (recompute)", dir); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_bwd_send<1>), dim3(std::min(cdiv(cdiv(b.n_own, 4), 4), 2048)), dim3(256), 0, 0, b); });
         hipLaunchKernelGGL((k_edge_bwd_send<4>), dim3(gridb), dim3(256), 0, 0, b);
-        nO = ha; nQ = ha; snap(S, nO, b.n_own); snap(Q, nQ, b.n_own); cmp("bwd dP slots=4", rO, nO, b.n_own); cmp("bwd Q slots=4", rQ, nQ, b.n_own);
+        nO = ha; nQ = ha; snap(S, nO, b.n_own); cmp("bwd dP slots=4", rO, nO, b.n_own);
         hipLaunchKernelGGL((k_edge_bwd_send<1>), dim3(std::min(cdiv(cdiv(b.n_own, 4), 4), 2048)), dim3(256), 0, 0, b);
-        snap(S, nO, b.n_own); snap(Q, nQ, b.n_own); cmp("bwd dP slots=1", rO, nO, b.n_own); cmp("bwd Q slots=1", rQ, nQ, b.n_own);
+        snap(S, nO, b.n_own); cmp("bwd dP slots=1", rO, nO, b.n_own);
     }
     return 0;
 }

@@ -1,52 +1,70 @@
 // micro-benchmark of k_wgrad job shapes (developer tool; not part of the library)
 #include "../../gcnn-cut-selector_amd/csrc/k_wgrad.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("hip error %d at %d\n", (int)e, __LINE__); return 1; } } while (0)
 static int cdiv(int a, int b) { return (a + b - 1) / b; }
-int main() {
-    const int NMAX = 32000;
-    float *x, *d, *q, *partial, *sx; int* seg;
-    CK(hipMalloc(&x, (size_t)6 * NMAX * 64 * 4)); CK(hipMalloc(&d, (size_t)6 * NMAX * 64 * 4)); CK(hipMalloc(&q, (size_t)NMAX * 64 * 4));
-    CK(hipMalloc(&partial, (size_t)4096 * WG_SLAB * 4)); CK(hipMalloc(&sx, 4)); CK(hipMalloc(&seg, (NMAX + 1) * 4));
-    CK(hipMemset(x, 0, (size_t)6 * NMAX * 64 * 4)); CK(hipMemset(d, 0, (size_t)6 * NMAX * 64 * 4)); CK(hipMemset(q, 0, (size_t)NMAX * 64 * 4));
-    CK(hipMemset(seg, 0, (NMAX + 1) * 4)); CK(hipMemset(sx, 0, 4));
-    struct Cfg { const char* name; int njobs; int n[6]; int extra[6]; };
+int main(int argc, char** argv) {
+    const int NMAX = 32000, NJ = 24;
+    const bool rnd = argc > 1 && atoi(argv[1]) != 0;   // random operands (default: zeros)
+    float *x, *d, *partial, *sx, *feat, *epart; int* seg;
+    const size_t nel = (size_t)NJ * NMAX * 64;
+    CK(hipMalloc(&x, nel * 4)); CK(hipMalloc(&d, nel * 4));
+    CK(hipMalloc(&partial, (size_t)8192 * WG_SLAB * 4)); CK(hipMalloc(&sx, 64)); CK(hipMalloc(&seg, (NMAX + 1) * 4));
+    CK(hipMalloc(&feat, (size_t)NMAX * 16 * 4)); CK(hipMalloc(&epart, (size_t)1024 * 15 * 64 * 4));
+    CK(hipMemset(x, 0, nel * 4)); CK(hipMemset(d, 0, nel * 4)); CK(hipMemset(feat, 0, (size_t)NMAX * 16 * 4));
+    CK(hipMemset(seg, 0, (NMAX + 1) * 4)); CK(hipMemset(sx, 0, 64));
+    if (rnd) {
+        std::vector<float> h(nel);
+        for (size_t i = 0; i < nel; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
+        CK(hipMemcpy(x, h.data(), nel * 4, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < nel; ++i) h[i] = (float)rand() / RAND_MAX - 0.5f;
+        CK(hipMemcpy(d, h.data(), nel * 4, hipMemcpyHostToDevice));
+    }
+    struct Cfg { const char* name; int njobs; int n[NJ]; int rows; int pad8; int emb; };
+    const int C = 16000, V = 32000, K = 1893;
+#define STEP {V, V, V, V, V, V, V, V, C, C, C, C, C, C, C, K, K, K, K, K, K, K}
     Cfg cfgs[] = {
-        {"1 plain job 32k", 1, {32000}, {0}},
-        {"1 deg job 32k", 1, {32000}, {1}},
-        {"1 q job 32k", 1, {32000}, {2}},
-        {"1 plain job 16k", 1, {16000}, {0}},
-        {"1 plain job 2k", 1, {1893}, {0}},
-        {"5 plain jobs 32k", 5, {32000, 32000, 32000, 32000, 32000}, {0, 0, 0, 0, 0}},
-        {"conv2-like", 6, {32000, 32000, 32000, 32000, 32000, 16000}, {0, 0, 0, 1, 0, 2}},
-        {"conv3-like", 6, {1893, 1893, 1893, 1893, 1893, 32000}, {0, 0, 0, 1, 0, 2}},
-        {"embed-like", 3, {16000, 32000, 1893}, {0, 0, 0}},
-        {"conv3 no extras", 6, {1893, 1893, 1893, 1893, 1893, 32000}, {0, 0, 0, 0, 0, 0}},
-        {"conv3 only q", 6, {1893, 1893, 1893, 1893, 1893, 32000}, {0, 0, 0, 0, 0, 2}},
-        {"conv3 only deg", 6, {1893, 1893, 1893, 1893, 1893, 32000}, {0, 0, 0, 1, 0, 0}},
-        {"1 deg job 2k", 1, {1893}, {1}},
-        {"1 q job 2k", 1, {1893}, {2}},
-        {"2 plain 32k", 2, {32000, 32000}, {0, 0}},
-        {"3 plain 32k", 3, {32000, 32000, 32000}, {0, 0, 0}},
+        {"1 job 32k", 1, {V}, 128, 0, 0},
+        {"1 job 2k", 1, {K}, 128, 0, 0},
+        {"5 jobs 32k", 5, {V, V, V, V, V}, 128, 0, 0},
+        {"step r=128", 22, STEP, 128, 0, 0},
+        {"step r=128 pad8", 22, STEP, 128, 1, 0},
+        {"step r=128 +emb1", 22, STEP, 128, 0, 1},
+        {"step r=192", 22, STEP, 192, 0, 0},
+        {"step r=192 +emb1", 22, STEP, 192, 0, 1},
+        {"step r=256", 22, STEP, 256, 0, 0},
+        {"step r=96", 22, STEP, 96, 0, 0},
+        {"step r=64", 22, STEP, 64, 0, 0},
+        {"step r=64 +emb1", 22, STEP, 64, 0, 1},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (auto& c : cfgs) {
-        WgArgs a; a.njobs = c.njobs; a.partial = partial; a.rows_per_wave = WG_ROWS; int blk = 0;
+        WgArgs a; a.njobs = c.njobs; a.partial = partial; a.rows_per_wave = c.rows; int blk = 0, slab = 0;
         for (int j = 0; j < c.njobs; ++j) {
-            a.job[j] = WgJob{x + (size_t)j * NMAX * 64, j == 1 ? sx : nullptr, d + (size_t)j * NMAX * 64, c.extra[j] == 1 ? seg : nullptr,
-                             c.n[j], blk, blk};
-            blk += cdiv(c.n[j], WG_ROWS * WG_WAVES);
+            a.job[j] = WgJob{x + (size_t)j * NMAX * 64, nullptr, d + (size_t)j * NMAX * 64, nullptr, c.n[j], blk, slab};
+            const int nb = cdiv(c.n[j], c.rows * WG_WAVES);
+            blk += c.pad8 ? (nb + 7) & ~7 : nb; slab += nb;
         }
         a.nblocks = blk;
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{}, DwRedArgs{});
+        Emb1Args e{};
+        if (c.emb) {
+            const int ns[3] = {C, V, K}, fs[3] = {4, 14, 6};
+            for (int i = 0; i < 3; ++i) {
+                e.job[e.njobs++] = Emb1Job{feat, sx, sx, d + (size_t)i * NMAX * 64, x + (size_t)i * NMAX * 64, epart, ns[i], fs[i], e.nblocks};
+                e.nblocks += cdiv(ns[i], EMB1_ROWS * WG_WAVES);
+            }
+        }
+        const int grid = blk + e.nblocks;
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, e, DwRedArgs{});
         CK(hipEventRecord(e0, 0));
         const int R = 50;
-        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(blk), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, Emb1Args{}, DwRedArgs{});
+        for (int i = 0; i < R; ++i) hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(64 * WG_WAVES), WG_WAVES * WG_SLAB * sizeof(float), 0, a, e, DwRedArgs{});
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("%-20s blocks %4d  %.2f us/launch\n", c.name, blk, ms * 1000 / R);
+        printf("%-20s blocks %4d (+%d emb1)  %.2f us/launch\n", c.name, blk, e.nblocks, ms * 1000 / R);
     }
     return 0;
 }
