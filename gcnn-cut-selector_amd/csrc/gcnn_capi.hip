@@ -41,6 +41,13 @@ struct PerDeviceOnce {
         return true;
     }
 };
+static int device_cus() {   // compute units of the current device (MI355X: 256); cached per device
+    static int cus[GCNN_MAX_DEVICES] = {};
+    int d = 0, v = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= GCNN_MAX_DEVICES) return 256;
+    if (cus[d] == 0) cus[d] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && v > 0) ? v : 256;
+    return cus[d];
+}
 // ---- per-launch timing (gcnn_profile_begin / gcnn_profile_end): bench.py's roofline_step block -----------------------------
 // While enabled every kernel launch of the library is bracketed by two HIP events on the launch stream.  A measuring aid for
 // one thread; off by default and then a single predictable branch per launch.
@@ -200,20 +207,15 @@ struct Work {
     float* dwp[3];        // per-block partials of d w_edge, one [GCNN_EDGE_DW_PARTS,64] array per convolution
     float* dwp2[3];       // ... and their pre-reduction to [GCNN_EDGE_DW_PARTS / DW_CHUNK, 64] (k_wgrad's third block type)
     float* nrow[3];          // per receiver and channel: number of active edges
-    float* emb_partial[3];
     float* score_partial; int score_nblk;
     double* stats; int* stat_ids;   // pretraining: per-block partial sums; explicit left ids of an edge set
-    int emb_nblk[3];
     size_t total;
 };
 static inline size_t al4(size_t x) { return (x + 3) & ~(size_t)3; }
 
-static size_t wg_slabs(const gcnn_dims* d) {  // total number of wgrad slabs over all 22 jobs
-    const int C = d->n_cons, V = d->n_vars, K = d->n_cuts;
-    const int bc = cdiv(C, WG_ROWS * WG_WAVES), bv = cdiv(V, WG_ROWS * WG_WAVES), bk = cdiv(K, WG_ROWS * WG_WAVES);
-    // jobs per row set (see gcnn_backward): cons 7, var 8, cut 7; 8 each leaves slack
-    return (size_t)bc * 8 + (size_t)bv * 8 + (size_t)bk * 8;
-}
+// weight-gradient slabs: one per block of the k_wgrad launch, which is sized to one resident round (place_wg) -- a constant bound
+#define WG_MAX_SLABS 1024
+static size_t wg_slabs(const gcnn_dims*) { return WG_MAX_SLABS; }
 
 static void carve(const gcnn_dims* d, float* base, Work* w) {
     const size_t C = d->n_cons, V = d->n_vars, K = d->n_cuts;
@@ -233,12 +235,6 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     for (int i = 0; i < 3; ++i) {
         w->dwp[i] = take((size_t)GCNN_EDGE_DW_PARTS * EMB); w->dwp2[i] = take((size_t)(GCNN_EDGE_DW_PARTS / DW_CHUNK) * EMB);
         w->nrow[i] = take(nrecv[i] * EMB);
-    }
-    const int nemb[3] = {d->n_cons, d->n_vars, d->n_cuts};
-    const int femb[3] = {4, 14, 6};
-    for (int i = 0; i < 3; ++i) {
-        w->emb_nblk[i] = cdiv(nemb[i], EMB1_ROWS * WG_WAVES);   // blocks = slabs
-        w->emb_partial[i] = take((size_t)w->emb_nblk[i] * (femb[i] + 1) * EMB);
     }
     w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
     w->stat_ids = (int*)take((size_t)std::max(d->n_cons_edges, d->n_cut_edges));
@@ -759,7 +755,7 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
 
 
 // ---- backward ---------------------------------------------------------------------------------------------------
-struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; };
+struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; const float *mask, *shift, *scale; int f; };
 struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
@@ -769,7 +765,13 @@ struct JobList {
 static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr,
                    int n, float* gw, float* gb, float* g2, float* /*partial*/) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
-    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2};
+    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2, nullptr, nullptr, nullptr, 0};
+}
+// first layer of an embedding: x = raw features [n][f], dmat = dE1 (unmasked), e1 = the layer's output (k_wgrad.hpp, EXTRA == 2)
+static void add_wg_emb1(JobList& jl, const float* x, const float* shift, const float* scale, const float* dmat, const float* e1,
+                        int n, int f, float* gw, float* gb) {
+    if (n <= 0) return;
+    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f};
 }
 // Order the collected jobs and give them their block ranges.  Several jobs read the same matrix (dZ1 feeds the gradients of
 // both halves of W1; a raw embedding X is the operand of up to three products): such jobs are placed next to each other,
@@ -781,26 +783,43 @@ static void place_wg(JobList& jl, float* partial) {
     int order[WG_MAX_JOBS], last = -1;
     for (int k = 0; k < jl.npend; ++k) {
         int pick = -1;
-        if (last >= 0)
+        static const int share = getenv("GCNN_WG_SHARE") ? atoi(getenv("GCNN_WG_SHARE")) : 1;   // tuning knob
+        if (last >= 0 && share)
             for (int i = 0; i < jl.npend && pick < 0; ++i)
                 if (!used[i] && jl.pend[i].n == jl.pend[last].n && (jl.pend[i].x == jl.pend[last].x || jl.pend[i].d == jl.pend[last].d)) pick = i;
         for (int i = 0; i < jl.npend && pick < 0; ++i)   // otherwise the longest job not yet placed (ties: collection order)
             if (!used[i]) { pick = i; for (int q = i + 1; q < jl.npend; ++q) if (!used[q] && jl.pend[q].n > jl.pend[pick].n) pick = q; }
         used[pick] = true; order[k] = last = pick;
     }
+    // Chunk size: the launch is ONE resident round -- two blocks (8 waves) per CU, every SIMD holding two waves of (nearly) the
+    // same length from start to end, so the MFMA pipes stay shared evenly and there is no second, partly filled round.
+    // Smallest chunk (a multiple of 16 rows, at least WG_ROWS) whose block count fits; each job then spreads its rows evenly.
+    const int slots = std::min(2 * device_cus(), WG_MAX_SLABS - WG_MAX_JOBS);
+    auto blocks_at = [&](int r) { long long t = 0; for (int k = 0; k < jl.npend; ++k) t += cdiv(jl.pend[k].n, r * WG_WAVES); return t; };
+    int rows = WG_ROWS;
+    if (blocks_at(rows) > slots) {   // bisect on multiples of 16
+        int lo = rows / 16, hi = lo;
+        while (blocks_at(hi * 16) > slots) hi *= 2;
+        while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (blocks_at(mid * 16) > slots) lo = mid; else hi = mid; }
+        rows = hi * 16;
+    }
+    static const int forced = getenv("GCNN_WG_ROWS") ? atoi(getenv("GCNN_WG_ROWS")) : 0;   // tuning knob (tools/README.md)
+    if (forced >= 16 && forced % 16 == 0 && blocks_at(forced) <= WG_MAX_SLABS) rows = forced;
     for (int k = 0; k < jl.npend; ++k) {
         const PendWg& q = jl.pend[order[k]];
         WgJob& j = jl.wg.job[jl.wg.njobs++];
-        const int nb = cdiv(q.n, jl.wg.rows_per_wave * WG_WAVES);   // blocks = slabs: four chunks each
+        const int nb = cdiv(q.n, rows * WG_WAVES);   // blocks = slabs: four chunks each
+        j.nb = nb; j.rows = (cdiv(q.n, nb * WG_WAVES) + 15) & ~15;
         j.x = q.x; j.sx = q.sx; j.d = q.d; j.seg_ptr = q.seg_ptr; j.n = q.n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
+        j.mask = q.mask; j.shift = q.shift; j.scale = q.scale; j.f = q.f;
         const float* src = partial + (size_t)jl.nslab * WG_SLAB;
-        jl.wg.nblocks += (nb + 7) & ~7; jl.nslab += nb;
+        jl.wg.nblocks += nb; jl.nslab += nb;
         auto rd = [&](const float* s, float* dst, int len) {
             RdJob& r = jl.rd.job[jl.rd.njobs++];
             r.src = s; r.dst = dst; r.nparts = nb; r.stride = WG_SLAB; r.len = len; r.blk0 = jl.rdblk;
             jl.rdblk += cdiv(len, EMB);
         };
-        rd(src, q.gw, EMB * EMB);
+        rd(src, q.gw, (q.f ? q.f : EMB) * EMB);   // first-layer kernel [f,64]: the first f rows of the slab
         if (q.gb) rd(src + EMB * EMB, q.gb, EMB);
         if (q.g2) rd(src + EMB * EMB + EMB, q.g2, EMB);
     }
@@ -890,11 +909,6 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     Work w; carve(d, workspace, &w);
     const Acts &A = w.a, &G = w.g;
     JobList jl; memset(&jl, 0, sizeof(jl)); jl.wg.partial = w.partial;
-    {   // weight-gradient chunk per wave: about 6,000 waves per launch, never below WG_ROWS (7/8/7 jobs on cons/var/cut rows)
-        const long long row_jobs = 7ll * d->n_cons + 8ll * d->n_vars + 7ll * d->n_cuts;
-        const long long want = (row_jobs + 6143) / 6144;
-        jl.wg.rows_per_wave = (int)std::min<long long>(4096, std::max<long long>(WG_ROWS, (want + WG_ROWS - 1) / WG_ROWS * WG_ROWS));
-    }
 
     // the reduction (re)writes every trainable gradient whenever all three node sets are non-empty; otherwise start from 0
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
@@ -952,30 +966,23 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         if ((rc = launch_tail_bwd(m, st))) return rc;
     }
     // Weight gradients: every operand pair now exists, so ALL of them go out as two grouped launches -- the 22 [64,64]
-    // products (MFMA) together with the three first embedding layers (VALU, K = f <= 14), then the fixed-order reduction of
+    // products and the three first embedding layers ([f,64], f <= 14: a quarter of the MFMAs), then the fixed-order reduction of
     // the slabs.  (Running them beside the critical path on side streams was slower: a cross-stream event edge costs
     // 7-14 us here.)
-    Emb1Args ea; memset(&ea, 0, sizeof(ea));
-    for (int i = 0; i < 3; ++i) {
-        if (em[i].n <= 0) continue;
-        ea.job[ea.njobs++] = Emb1Job{em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1,
-                                     w.emb_partial[i], em[i].n, em[i].f, ea.nblocks};
-        ea.nblocks += w.emb_nblk[i];
-        // kernel [f,64] and bias [64] are adjacent rows of the slab but separate (4-float aligned) tensors in the layout
-        add_rd(jl, w.emb_partial[i], grads + poff(em[i].pb + E_W1), w.emb_nblk[i], (em[i].f + 1) * EMB, em[i].f * EMB);
-        add_rd(jl, w.emb_partial[i] + em[i].f * EMB, grads + poff(em[i].pb + E_B1), w.emb_nblk[i], (em[i].f + 1) * EMB, EMB);
-    }
+    for (int i = 0; i < 3; ++i)   // kernel [f,64] and bias [64] are separate (4-float aligned) tensors in the layout
+        add_wg_emb1(jl, em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1, em[i].n, em[i].f,
+                    grads + poff(em[i].pb + E_W1), grads + poff(em[i].pb + E_B1));
     for (int i = 0; i < 3; ++i)
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
     place_wg(jl, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
     for (int k = jl.ndw; k < 3; ++k) jl.dw.blk0[k + 1] = jl.dw.blk0[k];
-    if (jl.wg.nblocks + ea.nblocks + jl.dw.blk0[3] > 0) {
+    if (jl.wg.nblocks + jl.dw.blk0[3] > 0) {
         static PerDeviceOnce attr;
         const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default
         if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ProfScope prof("k_wgrad", st);
-        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + ea.nblocks + jl.dw.blk0[3]), dim3(64 * WG_WAVES), smem, st, jl.wg, ea, jl.dw);
+        hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + jl.dw.blk0[3]), dim3(64 * WG_WAVES), smem, st, jl.wg, jl.dw);
         LAUNCHCHK();
     }
     const bool fuse_adam = adam && d->n_cons > 0 && d->n_vars > 0 && jl.rdblk > 0;

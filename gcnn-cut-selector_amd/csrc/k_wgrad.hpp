@@ -1,91 +1,52 @@
 #pragma once
 #include "gcnn_common.hpp"
 
-// ---------------------------------------------------------------------------------------------------------------
-// First embedding layer relu(((x+shift)*scale) @ W[f,64] + b) (model.py:174-177 and var/cut twins): its forward opens
-// the forward embedding programs (emb_program in k_rows.hpp); here its weight gradient on the VALU (K = f <= 14).
-// ---------------------------------------------------------------------------------------------------------------
-// gradient of the first embedding layer's weights: dW[f][j] = sum_r xn[r][f] * dPre[r][j], db[j] = sum_r dPre[r][j]
-// with dPre = dY * (Y > 0).  One WAVE per chunk of EMB1_ROWS rows, lane = output column; the four waves of a block add up
-// in LDS: per-block partial slab [(F+1)*64] (row F = bias).  The three embeddings (F = 4, 14, 6) are extra block ranges of the k_wgrad launch below.
-#define EMB1_ROWS 64
 #define WG_WAVES 4    // waves (= chunks) per block of the k_wgrad launch
-struct Emb1Job { const float* x; const float* shift; const float* scale; const float* dy; const float* yact; float* partial; int n; int f; int blk0; };
-struct Emb1Args { int njobs; int nblocks; Emb1Job job[3]; };
-
-template <int F>
-__device__ __forceinline__ void embed1_wgrad_body(const Emb1Job& jb, int blk, float* red) {
-    const int col = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float acc[F + 1], shift[F], scale[F];
-#pragma unroll
-    for (int f = 0; f <= F; ++f) acc[f] = 0.f;
-#pragma unroll
-    for (int f = 0; f < F; ++f) { shift[f] = jb.shift[f]; scale[f] = jb.scale[f]; }
-    const int r0 = min(jb.n, (blk * WG_WAVES + wv) * EMB1_ROWS);   // this wave's chunk (may be empty: zeros)
-    const int r1 = min(jb.n, r0 + EMB1_ROWS);
-#pragma unroll 8
-    for (int r = r0; r < r1; ++r) {
-        float d = jb.dy[(size_t)r * EMB + col];
-        d = jb.yact[(size_t)r * EMB + col] > 0.f ? d : 0.f;
-#pragma unroll
-        for (int f = 0; f < F; ++f) acc[f] = fmaf((jb.x[(size_t)r * F + f] + shift[f]) * scale[f], d, acc[f]);   // x: wave-uniform
-        acc[F] += d;
-    }
-    // the four waves of the block add up in LDS: one partial slab per block
-#pragma unroll
-    for (int f = 0; f <= F; ++f) red[wv * 15 * EMB + f * EMB + col] = acc[f];
-    __syncthreads();
-    for (int i = threadIdx.x; i < (F + 1) * EMB; i += 64 * WG_WAVES)
-        jb.partial[(size_t)blk * (F + 1) * EMB + i] = (red[i] + red[15 * EMB + i]) + (red[2 * 15 * EMB + i] + red[3 * 15 * EMB + i]);
-}
-__device__ __forceinline__ void embed1_wgrad_block(const Emb1Args& a, int b, float* red) {
-    int ji = 0;
-    while (ji + 1 < a.njobs && b >= a.job[ji + 1].blk0) ++ji;
-    const Emb1Job jb = a.job[ji];
-    const int blk = b - jb.blk0;
-    if (jb.f == 4) embed1_wgrad_body<4>(jb, blk, red);
-    else if (jb.f == 6) embed1_wgrad_body<6>(jb, blk, red);
-    else embed1_wgrad_body<14>(jb, blk, red);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradients: G[64,64] = sum_r (sx*X[r])^T D[r], db = sum_r D[r], dbd = sum_r deg_r D[r]     (B3/B4/B8/B11)
-// Grouped launch: one job per (X, D) pair, ONE WAVE per WG_ROWS-row chunk of a job; the four waves of a block take four
-// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 4 chunks.  Chunk = 128 rows at
-// setcov-500 x 32 (balances the 1,024 SIMDs better than 256; 64 drowns in prologue), scaled up with the row count so that
-// big row sets (capfac: 650 k rows) do not pay for tens of thousands of slabs.  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per instruction) and both operands come
-// straight from global memory, every row read exactly once as whole 256-B lines: lane (m, g) loads the float4 at columns
-// 4m..4m+3 of row 4*step+g of X and of D; component va of the X load and component vb of the D load feed accumulator
-// (va, vb), so two loads feed 16 MFMAs.  No LDS or barriers in the main loop; loads run one 16-row batch ahead of the MFMAs.
+// Grouped launch: one job per (X, D) pair, ONE WAVE per chunk of a job's rows; the four waves of a block take four
+// consecutive chunks and add their results up in LDS, so a block emits one partial slab per 4 chunks.  The host sizes the
+// chunks so that the whole launch is ONE resident round (two blocks per CU; gcnn_capi.hip, place_wg): every SIMD holds two
+// waves of nearly equal length from start to end.  Rows are the MFMA k dimension (v_mfma_f32_16x16x4_f32, four rows per
+// instruction) and both operands come straight from global memory, every row read exactly once as whole 256-B lines: lane
+// (m, g) loads the float4 at columns 4m..4m+3 of row 4*step+g of X and of D; component va of the X load and component vb of
+// the D load feed accumulator (va, vb), so two loads feed 16 MFMAs.  No LDS or barriers in the main loop; the loads of the
+// next 16-row batch are in flight while the 64 MFMAs of the current one issue (see wg_load / the scheduling barriers in
+// wg_body for what that takes).
 // Per-block partial slab [64*64 + 64 + 64] floats; summed in a fixed order by k_reduce (no atomics).
 // ---------------------------------------------------------------------------------------------------------------
-#define WG_ROWS 128   // smallest chunk; big row sets use a multiple (WgArgs.rows_per_wave) so the launch stays at a few thousand waves
+#define WG_ROWS 64    // smallest chunk (rows per wave)
 #define WG_SLAB (EMB * EMB + 2 * EMB)
-#define WG_MAX_JOBS 24
+#define WG_MAX_JOBS 28
 #define WG_STEPS 4   // 4-row MFMA steps per batch of loads
-struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; int n; int blk0; int slab0; };
-struct WgArgs { int njobs; int nblocks; int rows_per_wave; float* partial; WgJob job[WG_MAX_JOBS]; };
+// f > 0: the job is the FIRST layer of an embedding, relu(((x+shift)*scale) @ W[f,64] + b) (model.py:174-177 and twins):
+//        x = the raw features [n][f], d = dE1 still unmasked, mask = E1 (the ReLU output); G is [f,64] (rows >= f: zeros)
+struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float *mask, *shift, *scale;
+               int n; int blk0; int slab0; int f;
+               int nb, rows; };   // blocks of the job; rows per wave (a multiple of 16: the job's rows spread evenly over nb * 4 waves)
+struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
-struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
+struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS], k[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
 
-// EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f)
+// EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f),
+//        2 = first embedding layer: X^T has only f <= 14 (padded to 16) rows, so lane (m, g) loads ONE raw feature x[row][m]
+//            (normalised at use) as the A operand of the single accumulator row, and D is masked by the layer's output
+// Loads are UNCONDITIONAL (rows past the chunk are clamped to its last row and zeroed at use): a load under a branch would
+// make the number of loads in flight unknown to the compiler, which then waits for all of them (s_waitcnt vmcnt(0)) right
+// after issuing the next batch -- no overlap with the MFMAs at all.
 template <int EXTRA>
 __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int col) {
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) {
-        const int r = row0 + 4 * s + g;
-        t.x[s] = t.d[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-        t.p0[s] = t.p1[s] = 0;
-#ifdef WG_ABL_NOLOAD
-        if (r < rend && row0 < 0) {
-#else
-        if (r < rend) {
-#endif
-            t.x[s] = *(const float4*)(jb.x + (size_t)r * EMB + col);
-            t.d[s] = *(const float4*)(jb.d + (size_t)r * EMB + col);
-            if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
-        }
+        const int r = min(row0 + 4 * s + g, rend - 1);   // callers guarantee rend > 0
+        if (EXTRA == 2) {
+            t.x[s] = make_float4(jb.x[(size_t)r * jb.f + min(col >> 2, jb.f - 1)], 0.f, 0.f, 0.f);   // lanes m >= f: scale 0 below
+            t.k[s] = *(const float4*)(jb.mask + (size_t)r * EMB + col);
+        } else t.x[s] = *(const float4*)(jb.x + (size_t)r * EMB + col);
+        t.d[s] = *(const float4*)(jb.d + (size_t)r * EMB + col);
+        if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
     }
 }
 
@@ -96,16 +57,28 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i >> 2][i & 3] = f32x4w{0.f, 0.f, 0.f, 0.f};
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ce = cs;
+    float shift = 0.f, scale = 0.f;   // EXTRA == 2: this lane's feature (m); features >= f contribute zeros
+    if (EXTRA == 2 && m < jb.f) { shift = jb.shift[m]; scale = jb.scale[m]; }
     WgBatch cur, nxt;
-    wg_load<EXTRA>(cur, jb, rbeg, rend, g, col);
+    if (rbeg < rend) wg_load<EXTRA>(cur, jb, rbeg, rend, g, col);   // (an empty chunk stores a zero slab)
     for (int row0 = rbeg; row0 < rend; row0 += 4 * WG_STEPS) {
-        wg_load<EXTRA>(nxt, jb, row0 + 4 * WG_STEPS, rend, g, col);   // past the chunk: all lanes load nothing
+        wg_load<EXTRA>(nxt, jb, row0 + 4 * WG_STEPS, rend, g, col);   // past the chunk: re-reads its last row, unused
+        __builtin_amdgcn_sched_barrier(0);   // ... and the loads BEFORE them (the scheduler otherwise sinks them to their first use)
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
-            const float xa[4] = {cur.x[s].x, cur.x[s].y, cur.x[s].z, cur.x[s].w};
-            const float db[4] = {cur.d[s].x, cur.d[s].y, cur.d[s].z, cur.d[s].w};
+            const bool live = row0 + 4 * s + g < rend;
+            float xa[4] = {cur.x[s].x, cur.x[s].y, cur.x[s].z, cur.x[s].w};
+            float db[4] = {cur.d[s].x, cur.d[s].y, cur.d[s].z, cur.d[s].w};
 #pragma unroll
-            for (int va = 0; va < 4; ++va)
+            for (int v = 0; v < 4; ++v) { xa[v] = live ? xa[v] : 0.f; db[v] = live ? db[v] : 0.f; }
+            if (EXTRA == 2) {
+                xa[0] = (xa[0] + shift) * scale;
+                const float mk[4] = {cur.k[s].x, cur.k[s].y, cur.k[s].z, cur.k[s].w};
+#pragma unroll
+                for (int vb = 0; vb < 4; ++vb) db[vb] = mk[vb] > 0.f ? db[vb] : 0.f;
+            }
+#pragma unroll
+            for (int va = 0; va < (EXTRA == 2 ? 1 : 4); ++va)
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb)
 #ifdef WG_ABL_NOMFMA
@@ -119,16 +92,22 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
                 ce.x = fmaf(deg, db[0], ce.x); ce.y = fmaf(deg, db[1], ce.y); ce.z = fmaf(deg, db[2], ce.z); ce.w = fmaf(deg, db[3], ce.w);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // the copies below need the loads: keep them (and the wait) AFTER the MFMAs
         cur = nxt;
     }
     const float sx = jb.sx ? *jb.sx : 1.f;
-    // acc[va][vb][t] = G[4*(4g+t) + va][4m + vb]
-#pragma unroll
-    for (int va = 0; va < 4; ++va)
+    if (EXTRA == 2) {   // acc[0][vb][t] = G[4g + t][4m + vb]: 16 rows, the first f of them real
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            *(float4*)(slab + (4 * (4 * g + t) + va) * EMB + col) =
-                make_float4(acc[va][0][t] * sx, acc[va][1][t] * sx, acc[va][2][t] * sx, acc[va][3][t] * sx);
+            *(float4*)(slab + (4 * g + t) * EMB + col) = make_float4(acc[0][0][t], acc[0][1][t], acc[0][2][t], acc[0][3][t]);
+    } else {            // acc[va][vb][t] = G[4*(4g+t) + va][4m + vb]
+#pragma unroll
+        for (int va = 0; va < 4; ++va)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                *(float4*)(slab + (4 * (4 * g + t) + va) * EMB + col) =
+                    make_float4(acc[va][0][t] * sx, acc[va][1][t] * sx, acc[va][2][t] * sx, acc[va][3][t] * sx);
+    }
     // column sums: fold the four row slots (g) of the wave
     float* c8[8] = {&cs.x, &cs.y, &cs.z, &cs.w, &ce.x, &ce.y, &ce.z, &ce.w};
 #pragma unroll
@@ -162,7 +141,7 @@ __device__ __forceinline__ void dw_reduce_block(const DwRedArgs& d, int b, float
     if (part == 0) d.dst[c][(size_t)chunk * EMB + col] = (red[col] + red[EMB + col]) + (red[2 * EMB + col] + red[3 * EMB + col]);
 }
 
-__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e, DwRedArgs dw) {
+__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, DwRedArgs dw) {
     extern __shared__ __attribute__((aligned(16))) float wg_red[];   // [WG_WAVES][WG_SLAB]
     const int ndw = dw.blk0[3];
     if ((int)blockIdx.x < ndw) {   // the d w_edge pre-reduction first: a few short blocks, out of the way before the long chunks fill the chip
@@ -170,28 +149,33 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, Emb1Args e, D
         return;
     }
     const int bx = (int)blockIdx.x - ndw;
-    if (bx >= a.nblocks) {   // the (short) first-embedding-layer chunks come after the long MFMA chunks (measured: first is worse)
-        embed1_wgrad_block(e, bx - a.nblocks, wg_red);
-        return;
-    }
     int ji = 0;   // last job whose first block is <= this block: binary search (a linear scan is one dependent scalar load per job)
     for (int hi = a.njobs; hi - ji > 1;) {
         const int mid = (ji + hi) >> 1;
         if (bx >= a.job[mid].blk0) ji = mid; else hi = mid;
     }
     const WgJob jb = a.job[ji];
-    const int lb = bx - jb.blk0, wv = threadIdx.x >> 6;
-    if ((long long)lb * WG_WAVES * a.rows_per_wave >= jb.n) return;   // padding block (jobs start at multiples of 8 blocks): owns no rows, no slab
-    const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * a.rows_per_wave), rend = min(jb.n, rbeg + a.rows_per_wave);   // may be empty: zeros
+    // Which of the job's row blocks this block takes: rotated so that (row block) = (block index) mod 8 -- blocks are dealt to
+    // the eight XCDs round-robin, so the SAME rows of two jobs that share an operand (placed next to each other by the host:
+    // dZ1 feeds both halves of W1, a raw embedding X up to three products) are read on the same XCD at about the same time,
+    // and the second read is an L2 hit.  (All but at most 7 blocks of a job; padding jobs to 8-block boundaries instead
+    // unbalances the XCDs.)
+    const int wv = threadIdx.x >> 6;
+    int lb = bx - jb.blk0 + (jb.blk0 & 7) % jb.nb;
+    if (lb >= jb.nb) lb -= jb.nb;
+    const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * jb.rows), rend = min(jb.n, rbeg + jb.rows);   // may be empty: zeros
     float* mine = wg_red + wv * WG_SLAB;
-    if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);
+    if (jb.f) wg_body<2>(jb, mine, rbeg, rend);
+    else if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);
     else wg_body<0>(jb, mine, rbeg, rend);
     __syncthreads();
     float4* slab = (float4*)(a.partial + (size_t)(jb.slab0 + lb) * WG_SLAB);
-    for (int i = threadIdx.x; i < WG_SLAB / 4; i += 64 * WG_WAVES) {
-        const float4 p0 = ((const float4*)wg_red)[i], p1 = ((const float4*)(wg_red + WG_SLAB))[i];
-        const float4 p2 = ((const float4*)(wg_red + 2 * WG_SLAB))[i], p3 = ((const float4*)(wg_red + 3 * WG_SLAB))[i];
-        slab[i] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+    const int head = jb.f ? 16 * EMB / 4 : EMB * EMB / 4;   // float4s of G that hold anything (first-layer jobs: 16 rows)
+    for (int i = threadIdx.x; i < head + 2 * EMB / 4; i += 64 * WG_WAVES) {
+        const int q = i < head ? i : EMB * EMB / 4 + (i - head);
+        const float4 p0 = ((const float4*)wg_red)[q], p1 = ((const float4*)(wg_red + WG_SLAB))[q];
+        const float4 p2 = ((const float4*)(wg_red + 2 * WG_SLAB))[q], p3 = ((const float4*)(wg_red + 3 * WG_SLAB))[q];
+        slab[q] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
                               (p0.w + p1.w) + (p2.w + p3.w));
     }
 }
