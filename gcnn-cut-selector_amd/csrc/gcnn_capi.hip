@@ -488,6 +488,23 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
     for (int i = 0; i < ngroups; ++i) blk0[i + 1] = blk0[i] + nb[i];
     return nwaves;
 }
+// Few tiles (the cut rows of a training batch, every row set of a single-state inference call): one block of four waves per
+// tile, the waves sharing the tile's products (k_rows_split.hpp).  Blocks = tiles.
+static bool rows_split(const int* n, int ngroups, int* blk0) {
+    static const int max_tiles = getenv("GCNN_SPLIT_MAX_TILES") ? atoi(getenv("GCNN_SPLIT_MAX_TILES")) : 256;   // tuning knob (tools/README.md)
+    int total = 0;
+    blk0[0] = 0;
+    for (int i = 0; i < ngroups; ++i) { const int t = n[i] > 0 ? cdiv(n[i], 16) : 0; total += t; blk0[i + 1] = blk0[i] + t; }
+    return total <= max_tiles;
+}
+#define SPLIT_LAUNCH(NAME, KERNEL, GRID, SMEM, ST, ...)                                                                \
+    do {                                                                                                                \
+        ProfScope prof(NAME, ST);                                                                                       \
+        static PerDeviceOnce attr;                                                                                      \
+        if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024)); \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(256), SMEM, ST, __VA_ARGS__);                                       \
+        LAUNCHCHK();                                                                                                    \
+    } while (0)
 #define ROWS_LAUNCH(NAME, KERNEL8, KERNEL4, NWAVES, GRID, SMEM, ST, ...)                                                \
     do {                                                                                                                \
         ProfScope prof(NAME, ST);                                                                                       \
@@ -504,6 +521,15 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
 // `plan` (single-state inference, gcnn_infer): the plan's count step rides in this launch as extra blocks
 static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
     const int n[3] = {m.v.n, m.c.n, m.k.n}, ns[3] = {4, 3, 3};
+    if (rows_split(n, 3, m.blk0)) {
+        const size_t smem = EMB_SPLIT_LDS_FLOATS * sizeof(float);
+        if (plan) {
+            plan->blocks0 = std::min(cdiv(plan->s[0].n_edges + 1, 256), 32);
+            plan->blocks1 = std::min(cdiv(plan->s[1].n_edges + 1, 256), 8);
+            SPLIT_LAUNCH("k_infer_s1 (embeddings + plan: count)", (k_infer_s1<4, true>), m.blk0[3] + plan->blocks0 + plan->blocks1, smem, st, m, *plan);
+        } else if (m.blk0[3] > 0) SPLIT_LAUNCH("k_embed_fwd_split", k_embed_fwd_split, m.blk0[3], smem, st, m);
+        return 0;
+    }
     const int nwaves = rows_blocks(n, ns, 3, m.blk0);
     if (plan) {
         const int nt = nwaves * 64;
@@ -520,6 +546,23 @@ static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
 static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, hipStream_t st) {
     int blk0[2];
     const int ns = 4;
+    if (rows_split(&a.n, 1, blk0)) {
+        const size_t smem = CONV_SPLIT_LDS_FLOATS * sizeof(float);
+        if (plan && tail == CF_PROJ && plan->n_vars <= IPLAN_FUSE_MAX_VARS) {   // the plan's order step rides in this launch
+            const int grid = blk0[1] + std::min(cdiv(plan->n_vars, 16), 48);
+            if (grid > 0) SPLIT_LAUNCH("k_infer_s3 (conv row program + plan: order)", (k_infer_s3<4, true>), grid, smem, st, a, *plan, blk0[1]);
+            return 0;
+        }
+        if (plan && tail == CF_PROJ && plan->n_vars > 0) {
+            ProfScope prof("k_iplan_order", st);
+            hipLaunchKernelGGL(k_iplan_order, dim3(std::min(cdiv(plan->n_vars, 16), 2048)), dim3(256), 0, st, *plan);
+            LAUNCHCHK();
+        }
+        if (blk0[1] == 0) return 0;
+        if (tail == CF_READOUT) SPLIT_LAUNCH("k_conv_fwd<readout>", k_conv_fwd_split<CF_READOUT>, blk0[1], smem, st, a);
+        else SPLIT_LAUNCH("k_conv_fwd<proj>", k_conv_fwd_split<CF_PROJ>, blk0[1], smem, st, a);
+        return 0;
+    }
     const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
     const size_t smem = ROWS_LDS_FLOATS(5, 5) * sizeof(float);
     if (plan && tail == CF_PROJ && plan->n_vars <= IPLAN_FUSE_MAX_VARS) {   // the plan's order step rides in this launch
@@ -542,6 +585,11 @@ static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, 
 static int launch_conv_turn(const ConvFArgs& a, const ConvBArgs& b, hipStream_t st) {
     int blk0[2];
     const int ns = 10;
+    if (rows_split(&a.n, 1, blk0)) {
+        if (blk0[1] > 0)
+            SPLIT_LAUNCH("k_conv_turn (readout + loss head + cut-row gradients)", k_conv_turn_split, blk0[1], CONV_SPLIT_LDS_FLOATS * sizeof(float), st, a, b);
+        return 0;
+    }
     const int nwaves = rows_blocks(&a.n, &ns, 1, blk0);
     if (blk0[1] == 0) return 0;
     ROWS_LAUNCH("k_conv_turn (readout + loss head + cut-row gradients)", k_conv_turn<8>, k_conv_turn<4>, nwaves, blk0[1],

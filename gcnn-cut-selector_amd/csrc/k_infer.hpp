@@ -1,6 +1,7 @@
 #pragma once
 #include "gcnn_common.hpp"
 #include "k_rows.hpp"
+#include "k_rows_split.hpp"
 #include "k_edge.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -181,10 +182,18 @@ __global__ __launch_bounds__(256) void k_rank_scores(const float* __restrict__ s
 //   launch 1: embeddings            + count     launch 2: conv v->c edge pass + place     launch 3: conv v->c row program + order
 // -- three launches and three dependent kernel boundaries fewer per call (the SCIP plugin's call is latency, not throughput).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NWAVES>
+// SPLIT: the four-waves-per-tile programs of k_rows_split.hpp (few tiles; NWAVES == 4)
+template <int NWAVES, bool SPLIT = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_infer_s1(EmbGroupArgs m, IplanArgs ia) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
+    if (SPLIT) {
+        if (b < m.blk0[1]) emb_split<14, 2>(m.v, smem, b, m.blk0[1]);
+        else if (b < m.blk0[2]) emb_split<4, 1>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
+        else if (b < m.blk0[3]) emb_split<6, 1>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
+        else iplan_count_body(ia, b - m.blk0[3], NWAVES * 64);
+        return;
+    }
     if (b < m.blk0[1]) emb_program<14, 2, NWAVES * 64>(m.v, smem, b, m.blk0[1]);
     else if (b < m.blk0[2]) emb_program<4, 1, NWAVES * 64>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
     else if (b < m.blk0[3]) emb_program<6, 1, NWAVES * 64>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
@@ -199,10 +208,13 @@ __global__ __launch_bounds__(256) void k_infer_s2(EdgeArgs e, IplanArgs ia, int 
     const float s1 = *e.s1;
     if (s1 < 0.f) edge_fwd_impl<4, false, true>(e, s1, b, edge_blocks); else edge_fwd_impl<4, false, false>(e, s1, b, edge_blocks);
 }
-template <int NWAVES>
+template <int NWAVES, bool SPLIT = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_infer_s3(ConvFArgs a, IplanArgs ia, int conv_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
-    if (b < conv_blocks) convf_program<CF_PROJ, NWAVES * 64>(a, smem, b, conv_blocks);
+    if (b < conv_blocks) {
+        if (SPLIT) convf_split<CF_PROJ>(a, smem, b, conv_blocks);
+        else convf_program<CF_PROJ, NWAVES * 64>(a, smem, b, conv_blocks);
+    }
     else iplan_order_body<NWAVES * 64>(ia, b - conv_blocks, gridDim.x - conv_blocks);
 }

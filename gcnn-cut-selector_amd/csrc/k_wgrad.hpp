@@ -20,6 +20,9 @@
 #define WG_SLAB (EMB * EMB + 2 * EMB)
 #define WG_MAX_JOBS 28
 #define WG_STEPS 4   // 4-row MFMA steps per batch of loads
+#ifndef WG_RING
+#define WG_RING 2    // batches in the load ring (WG_RING - 1 in flight behind the one being multiplied; 3 and 4 measured: no gain)
+#endif
 // f > 0: the job is the FIRST layer of an embedding, relu(((x+shift)*scale) @ W[f,64] + b) (model.py:174-177 and twins):
 //        x = the raw features [n][f], d = dE1 still unmasked, mask = E1 (the ReLU output); G is [f,64] (rows >= f: zeros)
 struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float *mask, *shift, *scale;
@@ -59,11 +62,7 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ce = cs;
     float shift = 0.f, scale = 0.f;   // EXTRA == 2: this lane's feature (m); features >= f contribute zeros
     if (EXTRA == 2 && m < jb.f) { shift = jb.shift[m]; scale = jb.scale[m]; }
-    WgBatch cur, nxt;
-    if (rbeg < rend) wg_load<EXTRA>(cur, jb, rbeg, rend, g, col);   // (an empty chunk stores a zero slab)
-    for (int row0 = rbeg; row0 < rend; row0 += 4 * WG_STEPS) {
-        wg_load<EXTRA>(nxt, jb, row0 + 4 * WG_STEPS, rend, g, col);   // past the chunk: re-reads its last row, unused
-        __builtin_amdgcn_sched_barrier(0);   // ... and the loads BEFORE them (the scheduler otherwise sinks them to their first use)
+    auto compute = [&](const WgBatch& cur, int row0) {
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
             const bool live = row0 + 4 * s + g < rend;
@@ -92,8 +91,26 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
                 ce.x = fmaf(deg, db[0], ce.x); ce.y = fmaf(deg, db[1], ce.y); ce.z = fmaf(deg, db[2], ce.z); ce.w = fmaf(deg, db[3], ce.w);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // the copies below need the loads: keep them (and the wait) AFTER the MFMAs
-        cur = nxt;
+    };
+    // Ring of WG_RING batches, the loop unrolled WG_RING times so that no batch is ever copied (a copy of a batch still in
+    // flight would wait for it): while batch u is multiplied, the loads of the next WG_RING-1 batches are outstanding.  The
+    // loads are unconditional and outside every branch (the wait counts are exact); only the MFMAs of batches past the chunk
+    // are skipped (a wave-uniform branch).  The scheduling barriers keep each group of loads where it is written: the
+    // scheduler otherwise sinks them to their first use, i.e. behind the MFMAs they are meant to overlap.
+    constexpr int BR = 4 * WG_STEPS;   // rows per batch
+    WgBatch ring[WG_RING];
+    if (rbeg < rend) {   // (an empty chunk stores a zero slab)
+#pragma unroll
+        for (int u = 0; u < WG_RING - 1; ++u) wg_load<EXTRA>(ring[u], jb, rbeg + u * BR, rend, g, col);
+    }
+    for (int row0 = rbeg; row0 < rend; row0 += WG_RING * BR) {
+#pragma unroll
+        for (int u = 0; u < WG_RING; ++u) {
+            wg_load<EXTRA>(ring[(u + WG_RING - 1) % WG_RING], jb, row0 + (u + WG_RING - 1) * BR, rend, g, col);   // past the chunk: its last row again, unused
+            __builtin_amdgcn_sched_barrier(0);
+            if (row0 + u * BR < rend) compute(ring[u], row0 + u * BR);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     const float sx = jb.sx ? *jb.sx : 1.f;
     if (EXTRA == 2) {   // acc[0][vb][t] = G[4g + t][4m + vb]: 16 rows, the first f of them real
