@@ -140,12 +140,12 @@ def roofline_step(model, batch, targets, dev, steps=20):
         ("k_edge_fwd<count>", 1): ("conv c->v edge pass", 8.0 * E1 + row * (C + V) + 2 * row * V, 14.0 * 64 * E1, row * E1),
         ("k_conv_fwd<proj>", 1): ("conv c->v receiver update (V rows)", V * 6 * row, V * 5 * mm, 0),
         ("k_edge_fwd<count>", 2): ("conv v->k edge pass", 8.0 * E2 + row * (K + V) + 2 * row * K, 14.0 * 64 * E2, row * E2),
-        ("k_conv_fwd<loss>", 0): ("conv v->k receiver update + readout + MSE head (K rows)", K * 6 * row, K * 5 * mm, 0),
-        ("k_conv_bwd", 0): ("conv v->k receiver gradients (K rows)", K * 10 * row, K * 5 * mm, 0),
+        ("k_conv_turn (readout + loss head + cut-row gradients)", 0):
+            ("conv v->k receiver update + readout + MSE head + receiver gradients (K rows, one launch)", K * 13 * row, K * 10 * mm, 0),
         ("k_edge_bwd_send", 0): ("conv v->k sender gradients", 8.0 * E2 + 3 * row * V + 2 * row * K, 22.0 * 64 * E2, 2 * row * E2),
-        ("k_conv_bwd", 1): ("conv c->v receiver gradients (V rows) + cut tail", V * 10 * row + K * 5 * row, V * 5 * mm + K * 2 * mm, 0),
+        ("k_conv_bwd", 0): ("conv c->v receiver gradients (V rows) + cut tail", V * 10 * row + K * 5 * row, V * 5 * mm + K * 2 * mm, 0),
         ("k_edge_bwd_send", 1): ("conv c->v sender gradients", 8.0 * E1 + 3 * row * C + 2 * row * V, 22.0 * 64 * E1, 2 * row * E1),
-        ("k_conv_bwd", 2): ("conv v->c receiver gradients (C rows)", C * 10 * row, C * 5 * mm, 0),
+        ("k_conv_bwd", 1): ("conv v->c receiver gradients (C rows)", C * 10 * row, C * 5 * mm, 0),
         ("k_edge_bwd_send", 2): ("conv v->c sender gradients", 8.0 * E1 + 3 * row * V + 2 * row * C, 22.0 * 64 * E1, 2 * row * E1),
         ("k_tail_bwd", 0): ("embedding tails (V and C rows)", V * 6 * row + C * 5 * row, V * 3 * mm + C * 2 * mm, 0),
         ("k_wgrad", 0): ("22 weight-gradient products + 3 first layers", 2 * row * (7 * C + 8 * V + 7 * K) + row * (2 * V + C)
