@@ -191,8 +191,10 @@ typedef struct gcnn_adam_args {
 /* ---- forward + loss head in one pass (the training step's forward, model_trainer.py:269-271) -------------------
  * As gcnn_forward(save_for_backward = 1); the last launch also evaluates the MSE head on its own scores,
  *   loss = loss_scale * sum_k (score_k - targets_k)^2    (loss_scale = 1/n_cuts: Keras' mean),
- * and the gradient of the readout's Dense(64->1) w.r.t. that loss, leaving both in the workspace: follow with
- * gcnn_backward(d_scores = NULL, ..., loss_out).  Saves the separate gcnn_mse_loss launch and the first backward launch. */
+ * and the gradient of the readout's Dense(64->1) w.r.t. that loss, and -- the same rows, nothing in between -- the receiver-side
+ * gradients of the cut rows (through the readout's hidden layer and conv v->k's update), leaving all of them in the workspace:
+ * follow with gcnn_backward(d_scores = NULL, ..., loss_out), which starts at conv v->k's sender pass.  Saves the separate
+ * gcnn_mse_loss launch and the first two backward launches.  (A caller that only wants loss and scores may stop here.) */
 int gcnn_forward_loss(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
                       const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
                       float* workspace, size_t workspace_floats, float* scores, const float* targets,
