@@ -17,6 +17,12 @@
 // channel, the active edges N: dS[r] is constant over a receiver's segment, so dP_recv[r] = s1*dS[r]*N[r] -- the
 // receiver-ordered half of the backward pass is an element-wise epilogue of the row program that produces dS.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef EDGE_U
+#define EDGE_U 4    // independent row gathers per lane and step, forward pass
+#endif
+#ifndef EDGE_UB
+#define EDGE_UB 4   // ... sender-ordered backward pass (two gathers per edge)
+#endif
 struct EdgeArgs {
     const int* seg_ptr; const int* oth; const float* coef;
     const float* p_own; const float* p_oth;       // projected table of the segment owner [n_own,64] / of the other side (gathered)
@@ -73,20 +79,21 @@ __device__ __forceinline__ EdgeSum edge_fwd_partial(const EdgeArgs& a, const Edg
         int o = 0; float c = 0.f;
         if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
         const int cnt = min(G, end - base);
-        for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-            int oi[4]; float ci[4]; bool ok[4]; float4 p[4];
+        for (int i0 = 0; i0 < cnt; i0 += EDGE_U * SLOTS) {
+            int oi[EDGE_U]; float ci[EDGE_U]; bool ok[EDGE_U]; float4 p[EDGE_U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EDGE_U; ++u) {
                 const int i = i0 + u * SLOTS + slot;
                 ok[u] = i < cnt;
                 const int src = gbase + (ok[u] ? i : 0);
                 oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
             }
+            // unconditional gathers (a slot past the end re-reads the row of the group's first edge, unused): loads under a
+            // lane mask would hide from the compiler how many are in flight, and it would wait for each before the next
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
+            for (int u = 0; u < EDGE_U; ++u) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EDGE_U; ++u) {
                 if (ok[u]) {
                     float h0 = fmaf(ci[u], w.x, p[u].x) + pown.x, h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
                     float h2 = fmaf(ci[u], w.z, p[u].z) + pown.z, h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
@@ -224,23 +231,22 @@ __device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const
         int o = 0; float c = 0.f;
         if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
         const int cnt = min(G, end - base);
-        for (int i0 = 0; i0 < cnt; i0 += 4 * SLOTS) {
-            int oi[4]; float ci[4]; bool ok[4]; float4 d[4], q[4];
+        for (int i0 = 0; i0 < cnt; i0 += EDGE_UB * SLOTS) {
+            int oi[EDGE_UB]; float ci[EDGE_UB]; bool ok[EDGE_UB]; float4 d[EDGE_UB], q[EDGE_UB];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < EDGE_UB; ++v) {
                 const int i = i0 + v * SLOTS + slot;
                 ok[v] = i < cnt;
                 const int src = gbase + (ok[v] ? i : 0);
                 oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
             }
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (ok[v]) {
-                    d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
-                    q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
-                }
+            for (int v = 0; v < EDGE_UB; ++v) {   // unconditional, see edge_fwd_partial
+                d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
+                q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
+            }
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < EDGE_UB; ++v)
                 if (ok[v]) {
                     const float j0 = fmaf(ci[v], w.x, psend.x) + q[v].x, j1 = fmaf(ci[v], w.y, psend.y) + q[v].y;
                     const float j2 = fmaf(ci[v], w.z, psend.z) + q[v].z, j3 = fmaf(ci[v], w.w, psend.w) + q[v].w;

@@ -325,3 +325,40 @@ def test_adam_with_zero_global_cut_count_is_no_step(dev):
     t_dev = float(opt._dev[4])
     opt.apply_flat_dev(m, g, grad_scale=torch.ones(1, device=dev), divide=True)
     assert float(opt._dev[4]) == t_dev + 1
+
+
+_BITS_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from gcnn_cut_selector_amd import synthetic, utils
+from gcnn_cut_selector_amd.model import GCNN
+from gcnn_cut_selector_amd.trainer import TrainState, train_step
+from oracle import gcnn_oracle as O
+dev = torch.device("cuda", 0)
+params = O.randomize_params(O.init_params(31, np.float32), 32)
+m = GCNN(device=dev); m.set_weights([params[n] for n in O.PARAM_NAMES])
+state, y, _ = synthetic.make_batch("setcov", 6)
+batch = m.prepare(state); ts = TrainState(m)
+loss, scores = train_step(m, batch, torch.as_tensor(y).to(dev), None, ts)
+h = hashlib.sha256()
+h.update(ts.grads.cpu().numpy().tobytes()); h.update(scores.cpu().numpy().tobytes()); h.update(np.float32(float(loss)).tobytes())
+s1, _ = synthetic.make_sample("combauc", 2)
+h.update(m.score_state(utils.state_to_inputs(s1), rank=True).numpy().tobytes())
+print("BITS", h.hexdigest())
+"""
+
+
+def test_few_tile_programs_give_the_same_bits_as_the_one_wave_programs(dev):
+    """k_rows_split.hpp (four waves per tile; launches of <= 256 tiles: the training turnaround, single-state inference) keeps
+    the MFMA order per output element, so gradients, scores and loss must not change by one bit when it is switched off
+    (GCNN_SPLIT_MAX_TILES=0, read once per process -> two child processes)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for knob in ("256", "0"):
+        env = dict(os.environ, GCNN_SPLIT_MAX_TILES=knob)
+        r = subprocess.run([sys.executable, "-c", _BITS_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("BITS")][-1])
+    assert out[0] == out[1]
