@@ -1,6 +1,7 @@
 """Whole-model parity (GPU): the HIP GCNN against the CPU oracle on identical inputs and weights.
 Tolerance (BASELINE.json north star): scores within 1e-4 absolute of the fp32/fp64 restatement; gradients within
-5e-4 of the largest entry of each tensor (see _grad_check)."""
+1e-4 of the largest entry of each tensor -- or, where the reference's own fp32 arithmetic sits farther than that from fp64
+(ReLU branches decided by rounding), within twice that distance (see _grad_check)."""
 import numpy as np
 import pytest
 import torch
@@ -141,10 +142,13 @@ def test_forward_is_deterministic_and_training_flag_inert(dev):
     assert np.array_equal(a, b)
 
 
-def _grad_check(m, params, state, y, rtol=5e-4):
-    # Tolerance: fp32 kernels vs the fp64 oracle, relative to the largest entry of each tensor.  Besides summation-order
-    # noise (~1e-5) an fp32 ReLU pre-activation that lands within rounding of 0 can take the other branch than in fp64;
-    # one such edge moves a gradient entry by one edge's share (~1e-4 of the largest entry at these sizes).
+def _grad_check(m, params, state, y, rtol=1e-4):
+    # Tolerance: fp32 kernels vs the fp64 oracle, relative to the largest entry of each tensor: 1e-4 (measured on these cases:
+    # 2e-7 .. 5e-6, as close as or closer than torch's own fp32 evaluation of the restatement).  The exception is inherent to
+    # fp32: a ReLU pre-activation that lands within rounding of 0 can take the other branch than in fp64, and one such edge
+    # moves a gradient entry by that edge's whole share (capfac at scale 0.2: 5e-4 of the largest entry -- for the fp32
+    # restatement exactly as for the kernels).  So where the reference's arithmetic itself (fp32, restated) is farther than
+    # 1e-4 from fp64, the bound is twice ITS distance.
     pred = m(state, True)
     loss = ((pred - torch.as_tensor(y, device=pred.device)) ** 2).mean()
     m.flat_parameters.grad = None
@@ -162,7 +166,7 @@ def _grad_check(m, params, state, y, rtol=5e-4):
         err = np.abs(g - w).max()
         ref = max(np.abs(w).max(), 1e-6)
         fp32_gap = np.abs(want32[name].astype(np.float64) - w).max()
-        if not err <= max(rtol * ref, 3 * fp32_gap) + 1e-7:
+        if not err <= max(rtol * ref, 2 * fp32_gap) + 1e-7:
             bad.append((name, err, ref, fp32_gap))
     assert not bad, bad
 
