@@ -3,7 +3,7 @@
 #   bash tools/collect_sq.sh <outdir> [bench.py args]
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=$1; shift; mkdir -p $O
+O=$1; shift; mkdir -p $O; rm -rf $O/sq   # one run per directory: the report below reads the first counter file it finds
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/sq -- python3 bench.py --steps 6 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-roofline "$@" > $O/sq.log 2>&1
 python3 - $O <<'PY'
 import csv, sys, glob, collections
