@@ -456,7 +456,7 @@ int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const fl
 // dealt round-robin over a program's blocks and then over a block's waves (k_rows.hpp), so every SIMD of every block gets
 // the same number of tiles +-1.  Row sets too small for 256 full blocks still spread over all CUs; otherwise 256 blocks
 // split by work (tiles x stages).  (16 waves per block, four per SIMD, were measured and rejected: profiles/README.md.)
-static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) {
+static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0, int cap = 256) {
     int ntile[3], total = 0;
     for (int i = 0; i < ngroups; ++i) { ntile[i] = n[i] > 0 ? cdiv(n[i], 16) : 0; total += ntile[i]; }
     static const int forced = getenv("GCNN_ROWS_WAVES") ? atoi(getenv("GCNN_ROWS_WAVES")) : 0;   // tuning knob (tools/README.md)
@@ -468,17 +468,17 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0) 
         work[i] = (long long)ntile[i] * nstage[i]; sum_work += work[i];
     }
     // fewer than 256 blocks of this size: spread the tiles over all CUs instead (fewer tiles per block, idle waves are free)
-    const bool spread = sum_want < 256 && total > 1024;
+    const bool spread = sum_want < cap && total > 1024;
     int nb[3];
     for (int i = 0; i < ngroups; ++i) {
         nb[i] = want[i];
-        if ((sum_want > 256 || spread) && nb[i] > 0)
-            nb[i] = std::max(1, std::min(spread ? ntile[i] : want[i], (int)((256 * work[i] + sum_work - 1) / sum_work)));
+        if ((sum_want > cap || spread) && nb[i] > 0)
+            nb[i] = std::max(1, std::min(spread ? ntile[i] : want[i], (int)(((long long)cap * work[i] + sum_work - 1) / sum_work)));
     }
     // rounding each share up can leave 257 or 258 blocks for 256 CUs, and a block of a one-block-per-CU launch that has to wait
     // for a free CU adds its whole run time to the launch: take the excess from the largest group
-    if (sum_want > 256 || spread)
-        for (int total = nb[0] + (ngroups > 1 ? nb[1] : 0) + (ngroups > 2 ? nb[2] : 0); total > 256; --total) {
+    if (sum_want > cap || spread)
+        for (int total = nb[0] + (ngroups > 1 ? nb[1] : 0) + (ngroups > 2 ? nb[2] : 0); total > cap; --total) {
             int big = 0;
             for (int i = 1; i < ngroups; ++i) if (nb[i] > nb[big]) big = i;
             if (nb[big] <= 1) break;
@@ -530,7 +530,12 @@ static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
         } else if (m.blk0[3] > 0) SPLIT_LAUNCH("k_embed_fwd_split", k_embed_fwd_split, m.blk0[3], smem, st, m);
         return 0;
     }
-    const int nwaves = rows_blocks(n, ns, 3, m.blk0);
+    // the embedding programs stage three matrices (52 KB): two blocks fit a CU, and with many tiles per wave four waves per SIMD
+    // overlap the store-heavy epilogues with the MFMAs better than two (capfac x 32, indset x 64)
+    static const int cap_knob = getenv("GCNN_EMB_CAP") ? atoi(getenv("GCNN_EMB_CAP")) : 0;   // tuning knob
+    const int tiles = cdiv(std::max(m.v.n, 0), 16) + cdiv(std::max(m.c.n, 0), 16) + cdiv(std::max(m.k.n, 0), 16);
+    const int cap = cap_knob > 0 ? cap_knob : (tiles >= 8192 ? 512 : 256);
+    const int nwaves = rows_blocks(n, ns, 3, m.blk0, cap);
     if (plan) {
         const int nt = nwaves * 64;
         plan->blocks0 = std::min(cdiv(plan->s[0].n_edges + 1, nt), 32);   // few blocks, looping: they hold a CU slot of this launch's size
