@@ -307,7 +307,7 @@ int gcnn_collate(const gcnn_collate_job* jobs, int32_t n_jobs, const int64_t* sr
     a.src_off = (const long long*)src_off;
     a.dst_off = (const long long*)dst_off;
     a.batch = batch;
-    const int bx = (int)std::min<int64_t>(std::max<int64_t>((max_words + 1 + 1023) / 1024, 1), 2048);
+    const int bx = std::min(batch * COLLATE_CHUNKS, 2048);   // one block per (sample, chunk); larger batches loop
     hipLaunchKernelGGL(k_collate, dim3(bx, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
     LAUNCHCHK();
     return 0;
