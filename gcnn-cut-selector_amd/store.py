@@ -56,6 +56,7 @@ class SampleStore:
         self._maxdeg = [[[], []] for _ in range(2)]    # per edge set: longest by-left / by-variable segment of every sample
         self._final = False
         self._ring, self._ring_pos = [], 0
+        self._jobs = None                              # the collate jobs (sources, kinds, widths), built by the first batch
 
     # ---- ingestion ---------------------------------------------------------------------------------------------
     @classmethod
@@ -191,26 +192,32 @@ class SampleStore:
             total += (n + 63) & ~63
         buf = torch.empty(max(total, 64), dtype=torch.int32, device=dev)
         view = lambda name: buf[pos[name][0]:pos[name][0] + pos[name][1]]
-        jobs = (_lib.CollateJob * 16)()
-        nj = 0
+        # the 16 copy jobs: source, kinds and widths never change (built once); only the destinations move with the batch
+        if self._jobs is None:
+            names, jobs = [], (_lib.CollateJob * 16)()
 
-        def job(src, name, kind, width, add=-1, is_ptr=0):
-            nonlocal nj
-            jobs[nj] = _lib.CollateJob(src.data_ptr() if src.numel() else 0, view(name).data_ptr(), kind, width, add, is_ptr)
-            nj += 1
+            def job(src, name, kind, width, add=-1, is_ptr=0):
+                jobs[len(names)] = _lib.CollateJob(src.data_ptr() if src.numel() else 0, 0, kind, width, add, is_ptr)
+                names.append(name)
 
-        job(self.cons_feats, "cons_feats", _K_CONS, 4)
-        job(self.var_feats, "var_feats", _K_VAR, 14)
-        job(self.cut_feats, "cut_feats", _K_CUT, 6)
-        job(self.improvements, "improvements", _K_CUT, 1)
-        for slot, (kl, ke) in enumerate(((_K_CONS, _K_E1), (_K_CUT, _K_E2))):
-            g = self.graphs[slot]
-            job(g["l_ptr"], f"{slot}.l_ptr", kl, 1, ke, 1)
-            job(g["l_oth"], f"{slot}.l_oth", ke, 1, _K_VAR)
-            job(g["l_coef"], f"{slot}.l_coef", ke, 1)
-            job(g["v_ptr"], f"{slot}.v_ptr", _K_VAR, 1, ke, 1)
-            job(g["v_oth"], f"{slot}.v_oth", ke, 1, kl)
-            job(g["v_coef"], f"{slot}.v_coef", ke, 1)
+            job(self.cons_feats, "cons_feats", _K_CONS, 4)
+            job(self.var_feats, "var_feats", _K_VAR, 14)
+            job(self.cut_feats, "cut_feats", _K_CUT, 6)
+            job(self.improvements, "improvements", _K_CUT, 1)
+            for slot, (kl, ke) in enumerate(((_K_CONS, _K_E1), (_K_CUT, _K_E2))):
+                g = self.graphs[slot]
+                job(g["l_ptr"], f"{slot}.l_ptr", kl, 1, ke, 1)
+                job(g["l_oth"], f"{slot}.l_oth", ke, 1, _K_VAR)
+                job(g["l_coef"], f"{slot}.l_coef", ke, 1)
+                job(g["v_ptr"], f"{slot}.v_ptr", _K_VAR, 1, ke, 1)
+                job(g["v_oth"], f"{slot}.v_oth", ke, 1, kl)
+                job(g["v_coef"], f"{slot}.v_coef", ke, 1)
+            self._jobs = (jobs, names)
+        jobs, names = self._jobs
+        base = buf.data_ptr()
+        for i, name in enumerate(names):
+            jobs[i].dst = base + 4 * pos[name][0]
+        nj = len(names)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().gcnn_collate(jobs, nj, C.c_void_p(tab.data_ptr()), C.c_void_p(tab.data_ptr() + 8 * 5 * b),
                                                b, max(n for _, n in spec), _stream(dev)), "gcnn_collate")
