@@ -91,10 +91,13 @@ __device__ __forceinline__ EdgeSum edge_fwd_partial(const EdgeArgs& a, const Edg
                 const int src = gbase + (ok[u] ? i : 0);
                 oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
             }
-            // unconditional gathers (a slot past the end re-reads the row of the group's first edge, unused): loads under a
-            // lane mask would hide from the compiler how many are in flight, and it would wait for each before the next
+            // Wide lane groups (mean degree >= 12): unconditional gathers -- a slot past the end re-reads the row of the
+            // group's first edge, unused -- because loads under a lane mask hide from the compiler how many are in flight.
+            // SLOTS == 1 serves graphs of degree 2-3 (capfac, indset), where most slots of a step are past the end and the
+            // wasted gathers cost more than the waits (capfac x 32: +2 % per step when unconditional).
 #pragma unroll
-            for (int u = 0; u < EDGE_U; ++u) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
+            for (int u = 0; u < EDGE_U; ++u)
+                if (SLOTS > 1 || ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
 #pragma unroll
             for (int u = 0; u < EDGE_U; ++u) {
                 if (ok[u]) {
@@ -244,10 +247,11 @@ __device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const
                 oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
             }
 #pragma unroll
-            for (int v = 0; v < EDGE_UB; ++v) {   // unconditional, see edge_fwd_partial
-                d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
-                q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
-            }
+            for (int v = 0; v < EDGE_UB; ++v)   // unconditional for wide lane groups, see edge_fwd_partial
+                if (SLOTS > 1 || ok[v]) {
+                    d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
+                    q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
+                }
 #pragma unroll
             for (int v = 0; v < EDGE_UB; ++v)
                 if (ok[v]) {
