@@ -1,0 +1,44 @@
+"""Randomised parity sweep (GPU): random bipartite states of random sizes -- isolated nodes, duplicate entries, unsorted COO,
+one-row sets, cut counts around the 16-row tile size and the four-waves-per-tile threshold -- forward, inference and backward
+against the fp64 oracle, with the tolerances of tests/test_gpu_model.py.  python tools/stress_parity.py [cases] [seed]"""
+import os, sys
+import numpy as np
+import torch
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from oracle import gcnn_oracle as O  # noqa: E402  (checker only)
+from test_gpu_model import _grad_check, _model  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda", 0)
+m, params = _model(11, dev)
+p64 = {k: v.astype(np.float64) for k, v in params.items()}
+worst = 0.0
+for case in range(cases):
+    C = int(rng.choice([1, 2, 15, 16, 17, 100, 1000, 5000]) if rng.random() < .5 else rng.integers(1, 6000))
+    V = int(rng.choice([1, 3, 16, 33, 500, 4097]) if rng.random() < .5 else rng.integers(1, 9000))
+    K = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 255, 256, 257, 4095, 4096, 4097, 4200]) if rng.random() < .6 else rng.integers(1, 5000))
+    e1 = int(rng.integers(0, 20 * max(C, V))); e2 = int(rng.integers(0, 12 * max(K, 8)))
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    # skewed degrees: a few hub rows / hub variables
+    def ends(n, e):
+        a = rng.integers(0, n, e)
+        if e and rng.random() < .5: a[: e // 3] = rng.integers(0, max(1, n // 50 + 1), e // 3)
+        return a
+    cei = np.stack([ends(C, e1), ends(V, e1)]).astype(np.int32)
+    kei = np.stack([ends(K, e2), ends(V, e2)]).astype(np.int32)
+    if rng.random() < .5:   # (row, col)-sorted like get_state, else arbitrary order
+        o = np.lexsort((cei[1], cei[0])); cei = cei[:, o]
+        o = np.lexsort((kei[1], kei[0])); kei = kei[:, o]
+    state = (f(C, 4), cei, f(e1, 1), f(V, 14), f(K, 6), kei, f(e2, 1), C, V, K)
+    y = rng.uniform(0, 0.2, K)
+    want = O.scores(p64, state, torch.float64)
+    with torch.no_grad():
+        got = m(state, False).numpy()
+    err = float(np.abs(got - want).max()) if K else 0.0
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4), (case, C, V, K, e1, e2, err)
+    _grad_check(m, params, state, y)
+    worst = max(worst, err)
+    print(f"case {case:3d}  C={C:5d} V={V:5d} K={K:5d} E1={e1:6d} E2={e2:6d}  max|score err| {err:.2e}", flush=True)
+print(f"{cases} cases ok, worst score error {worst:.2e}")
