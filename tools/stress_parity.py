@@ -62,6 +62,14 @@ for case in range(cases):
             flips.append(f"{name} {rel:.1e} (one column: {int(cols.argmax())})")
             continue
         if rel > max(1e-4, 3 * gap32): flips.append(f"{name} {rel:.1e}")
+    # the fused training step (forward + MSE head + cut-row turnaround in one launch, backward from there) against the autograd path
+    from gcnn_cut_selector_amd.trainer import TrainState, train_step
+    batch = m.prepare(state)
+    ts = TrainState(m)
+    loss2, scores2 = train_step(m, batch, torch.as_tensor(y, dtype=torch.float32).to(dev), None, ts)
+    ga, gf = m.flat_parameters.grad.cpu().numpy(), ts.grads.cpu().numpy()
+    assert np.allclose(gf, ga, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(ga).max()))), (case, "fused step vs autograd", float(np.abs(gf - ga).max()))
+    assert abs(float(loss2) - want_loss) <= 1e-4 * max(1.0, abs(want_loss)), (case, "fused loss")
     q = m.score_state(state, rank=True)   # the one-call inference path (falls back to the general path for unsorted lists)
     assert np.allclose(q.numpy(), want, rtol=1e-4, atol=1e-4), (case, "score_state")
     assert list(q.rankings) == sorted(range(K), key=lambda i: q[i], reverse=True), (case, "ranking")
