@@ -22,7 +22,9 @@
 // ---------------------------------------------------------------------------------------------------------------
 #define IPLAN_MAX_VARS 32768   // the per-block scan of the counts lives in LDS (128 KB)
 #define IPLAN_MAX_DEG 2048
+#ifndef IPLAN_FUSE_MAX_VARS
 #define IPLAN_FUSE_MAX_VARS 4096   // above: place / order as launches of their own (small LDS footprint, all lane groups resident)
+#endif
 
 struct IplanSet { int* inds; int n_edges, n_left; int* l_ptr; };   // inds = [2,E]: left ids then variable ids
 struct IplanArgs {
