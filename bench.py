@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks ITSELF: the parent never
+touches the GPU, starts N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relays rank
+0's JSON line and exits non-zero if any child fails or if the line does not show N ranks on N distinct devices.  Under
+torch.distributed.run the ranks already exist; `--gpus` must then equal WORLD_SIZE.
+
 A step = forward + MSE + backward (+ one RCCL all-reduce of the flat gradient buffer when N > 1) + Keras-form Adam on one
 stacked synthetic batch already resident in HBM.  Weak scaling (default): 32 setcov-500 samples PER GPU.  Strong scaling:
 the global batch of 32 is split over the ranks by edge count (`parallel.shard_samples`).  Rank 0 prints ONE JSON line.
@@ -28,17 +33,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+# numpy / torch are imported by the worker only: the launcher (`--gpus N` without WORLD_SIZE) must stay off the GPU
 
 HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured streaming-copy ceiling
 MFMA_F32_PEAK_TF = 157.3    # dense fp32 MFMA = fp32 vector peak
 METRIC = "bipartite-graph edges/sec (fwd+bwd) per training step, setcov-500 batch=32"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE if set, else 1")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--problem", default="setcov", choices=["setcov", "combauc", "capfac", "indset"])
@@ -48,7 +52,99 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the step once and replay it as a hipGraph (measured: no faster than eager issue -- the GPU-side dependency chain is the limit, not the host)")
-    return ap.parse_args()
+    ap.add_argument("--stub-worker", action="store_true", help=argparse.SUPPRESS)   # tests/test_host.py: ranks on CPU over gloo, no GPU work
+    return ap.parse_args(argv)
+
+
+def _import_heavy():
+    global np, torch
+    import numpy as np
+    import torch
+
+
+# ---- launcher: `python bench.py --gpus N` starts the N ranks itself ---------------------------------------------------------
+def check_line(line, n):
+    """The JSON line of an N-rank run must show N ranks on N distinct devices; returns a reason string or None."""
+    try:
+        out = json.loads(line)
+    except (TypeError, ValueError):
+        return "rank 0 printed no JSON line"
+    d = out.get("distributed") or {}
+    ranks = d.get("ranks") or []
+    if out.get("n_gpus") != n or d.get("world_size_observed") != n or len(ranks) != n:
+        return f"asked for {n} ranks, the line reports n_gpus={out.get('n_gpus')}, world_size_observed={d.get('world_size_observed')}, {len(ranks)} rank records"
+    if len({r.get("uuid") or r.get("device") for r in ranks}) != n:
+        return f"{n} ranks share devices: " + ", ".join(f"rank {r.get('rank')} -> {r.get('uuid') or r.get('device')}" for r in ranks)
+    return None
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-rank run.  Makes no HIP / torch call (it does not even import torch): every rank is a fresh
+    `python bench.py ...` child with the usual torch.distributed environment; no exec, nothing is re-launched."""
+    import socket
+    import subprocess
+    with socket.socket() as s:   # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    failed = None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is not None:
+                live.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+        time.sleep(0.05)
+    if failed is not None:   # one rank is gone: its peers would wait in a collective for ever
+        for r in live:
+            procs[r].terminate()
+        for r in live:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        print(f"[bench] rank {failed[0]} exited with code {failed[1]}; run aborted", file=sys.stderr)
+        return 1
+    reader.join(timeout=10)
+    line = next((ln.strip() for ln in reversed(lines) if ln.lstrip().startswith("{")), None)
+    why = check_line(line, n)
+    if why:
+        print(f"[bench] invalid {n}-rank run: {why}", file=sys.stderr)
+        if line:
+            print(line, file=sys.stderr)
+        return 2
+    print(line, flush=True)
+    return 0
+
+
+def stub_worker(args, world, rank):
+    """Stand-in rank for the launcher test (no GPU): gloo rendezvous from the environment the launcher set, one all-gather of
+    rank records, rank 0 prints a line of the real shape.  GCNN_BENCH_STUB_FAIL=<rank> makes that rank exit 3 instead;
+    GCNN_BENCH_STUB_SAME_DEVICE=1 makes every rank report the same device."""
+    import torch.distributed as dist
+    if os.environ.get("GCNN_BENCH_STUB_FAIL") == str(rank):
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    me = {"rank": rank, "device": int(os.environ["LOCAL_RANK"]),
+          "uuid": "stub-0" if os.environ.get("GCNN_BENCH_STUB_SAME_DEVICE") == "1" else f"stub-{os.environ['LOCAL_RANK']}"}
+    got = [None] * world
+    dist.all_gather_object(got, me)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub",
+                          "distributed": {"world_size_env": world, "world_size_observed": dist.get_world_size(), "ranks": got}}), flush=True)
+    dist.destroy_process_group()
 
 
 def event_time_ms(fn, iters, warmup=3):
@@ -90,7 +186,7 @@ def roofline_scatter_sum(batch, dev):
     # HBM bytes per launch: NOT measured in this run -- PMC counters need rocprofv3 around the process.  The figure of the
     # committed FETCH_SIZE / WRITE_SIZE passes over this same kernel and shape is attached, with its source.
     traffic, source = None, None
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and (e, r) == (800000, 16000):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
@@ -131,27 +227,38 @@ def roofline_step(model, batch, targets, dev, steps=20):
                 order.append(key)
             per[key].append(ms * 1e3)
     row, mm = 256.0, 2.0 * 64 * 64
-    # (kernel, occurrence) -> (what, HBM bytes, FLOPs, L2-gathered bytes)
+    # (kernel, occurrence) -> (what, HBM bytes, FLOPs, L2-gathered bytes).  HBM bytes = the MINIMUM a launch must move: every
+    # DISTINCT [N,64] fp32 tensor it reads or writes counted once (256 B per row), edge lists 8 B per edge, raw features.
+    # k_wgrad reads several tensors in more than one job (dZ1 feeds both halves of W1, a raw embedding X up to three
+    # products): `hbm_bytes` counts each once (13 / 14 / 13 distinct tensors per constraint / variable / cut row: 6 X operands
+    # and 7 / 8 / 7 D operands) plus the raw features, the segment offsets and the partial slabs it writes;
+    # `hbm_bytes_per_job` charges every job its own operands (16 / 18 / 16 per row) -- what the launch would move if no
+    # second read hit L2.  PMC traffic (FETCH_SIZE + WRITE_SIZE) lies between the two.
+    wg_min = row * (13 * C + 14 * V + 13 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 4.0 * (C + V + K)
+    wg_job = row * (16 * C + 18 * V + 16 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 4.0 * (C + V + K)
+    wg_flops = mm * (7 * C + 8 * V + 7 * K) + 2.0 * 16 * 64 * (C + V + K)
+    edge_f = lambda e, own, oth: 8.0 * e + row * (own + oth) + 2 * row * own    # tables in, S + N out, (index, coef) per edge
+    edge_b = lambda e, own, oth: 8.0 * e + row * (own + 2 * oth) + row * own    # P_send, P_recv + dS in, dP_send out
     model_of = {
         ("k_embed_fwd", 0): ("3 embeddings + 4 projections", V * (56 + 4 * row) + C * (16 + 3 * row) + K * (24 + 3 * row),
                              V * (2 * 14 * 64 + 3 * mm) + C * (2 * 4 * 64 + 2 * mm) + K * (2 * 6 * 64 + 2 * mm), 0),
-        ("k_edge_fwd<count>", 0): ("conv v->c edge pass", 8.0 * E1 + row * (C + V) + 2 * row * C, 14.0 * 64 * E1, row * E1),
+        ("k_edge_fwd<count>", 0): ("conv v->c edge pass", edge_f(E1, C, V), 14.0 * 64 * E1, row * E1),
         ("k_conv_fwd<proj>", 0): ("conv v->c receiver update (C rows)", C * 6 * row, C * 5 * mm, 0),
-        ("k_edge_fwd<count>", 1): ("conv c->v edge pass", 8.0 * E1 + row * (C + V) + 2 * row * V, 14.0 * 64 * E1, row * E1),
+        ("k_edge_fwd<count>", 1): ("conv c->v edge pass", edge_f(E1, V, C), 14.0 * 64 * E1, row * E1),
         ("k_conv_fwd<proj>", 1): ("conv c->v receiver update (V rows)", V * 6 * row, V * 5 * mm, 0),
-        ("k_edge_fwd<count>", 2): ("conv v->k edge pass", 8.0 * E2 + row * (K + V) + 2 * row * K, 14.0 * 64 * E2, row * E2),
+        ("k_edge_fwd<count>", 2): ("conv v->k edge pass", edge_f(E2, K, V), 14.0 * 64 * E2, row * E2),
+        ("k_edge_fwd_block<count>", 0): ("conv v->k edge pass (a block per cut row)", edge_f(E2, K, V), 14.0 * 64 * E2, row * E2),
         ("k_conv_turn (readout + loss head + cut-row gradients)", 0):
             ("conv v->k receiver update + readout + MSE head + receiver gradients (K rows, one launch)", K * 13 * row, K * 10 * mm, 0),
-        ("k_edge_bwd_send", 0): ("conv v->k sender gradients", 8.0 * E2 + 3 * row * V + 2 * row * K, 22.0 * 64 * E2, 2 * row * E2),
+        ("k_edge_bwd_send", 0): ("conv v->k sender gradients", edge_b(E2, V, K), 22.0 * 64 * E2, 2 * row * E2),
         ("k_conv_bwd", 0): ("conv c->v receiver gradients (V rows) + cut tail", V * 10 * row + K * 5 * row, V * 5 * mm + K * 2 * mm, 0),
-        ("k_edge_bwd_send", 1): ("conv c->v sender gradients", 8.0 * E1 + 3 * row * C + 2 * row * V, 22.0 * 64 * E1, 2 * row * E1),
+        ("k_edge_bwd_send", 1): ("conv c->v sender gradients", edge_b(E1, C, V), 22.0 * 64 * E1, 2 * row * E1),
         ("k_conv_bwd", 1): ("conv v->c receiver gradients (C rows)", C * 10 * row, C * 5 * mm, 0),
-        ("k_edge_bwd_send", 2): ("conv v->c sender gradients", 8.0 * E1 + 3 * row * V + 2 * row * C, 22.0 * 64 * E1, 2 * row * E1),
+        ("k_edge_bwd_send", 2): ("conv v->c sender gradients", edge_b(E1, V, C), 22.0 * 64 * E1, 2 * row * E1),
         ("k_tail_bwd", 0): ("embedding tails (V and C rows)", V * 6 * row + C * 5 * row, V * 3 * mm + C * 2 * mm, 0),
-        ("k_wgrad", 0): ("22 weight-gradient products + 3 first layers", 2 * row * (7 * C + 8 * V + 7 * K) + row * (2 * V + C)
-                         + 2 * row * (C + V + K) + 4.0 * (4 * C + 14 * V + 6 * K),
-                         mm * (7 * C + 8 * V + 7 * K) + 2.0 * 64 * (5 * C + 15 * V + 7 * K), 0),
+        ("k_wgrad", 0): ("22 weight-gradient products + 3 first layers", wg_min, wg_flops, 0),
     }
+    pmc = step_traffic(d)
     out = []
     for key in order:
         us = float(np.median(per[key]))
@@ -162,13 +269,40 @@ def roofline_step(model, batch, targets, dev, steps=20):
             fh, fm = gbs / HBM_PEAK_GBS, tf / MFMA_F32_PEAK_TF
             entry.update({"what": what, "hbm_bytes": round(nbytes), "flops": round(flops), "GBs": round(gbs, 1), "TFs": round(tf, 2),
                           "bound": "hbm" if fh >= fm else "mfma", "frac": round(max(fh, fm), 4)})
+            if key[0] == "k_wgrad":
+                entry["hbm_bytes_per_job"] = round(wg_job)
+                entry["frac_per_job_bytes"] = round(max(wg_job / us / 1e3 / HBM_PEAK_GBS, fm), 4)
             if l2:
                 entry["l2_gather_bytes"] = round(l2)
                 entry["l2_gather_GBs"] = round(l2 / us / 1e3, 1)
+        if pmc is not None and len(pmc["launches"]) == len(order):   # same launch sequence: attach by position
+            rec = pmc["launches"][len(out)]
+            entry["traffic"] = round(rec["fetch_bytes"] + rec["write_bytes"])
+            entry["traffic_kernel"] = rec["kernel"]
         out.append(entry)
-    return {"steps_profiled": steps, "kernel_us_per_step": round(sum(e["us"] for e in out), 1), "launches": out,
-            "note": "HIP events recorded by the library around each launch (gcnn_profile_begin/end); medians over steps_profiled "
-                    "steps; event brackets add a few us of launch gaps, so the sum exceeds the un-instrumented step"}
+    res = {"steps_profiled": steps, "kernel_us_per_step": round(sum(e["us"] for e in out), 1), "launches": out,
+           "hbm_bytes": "minimum per launch: every distinct tensor read or written once (k_wgrad: also hbm_bytes_per_job, every job "
+                        "charged its own operands; PMC traffic lies between the two because shared operands hit L2)",
+           "note": "HIP events recorded by the library around each launch (gcnn_profile_begin/end); medians over steps_profiled "
+                   "steps; event brackets add a few us of launch gaps, so the sum exceeds the un-instrumented step"}
+    if pmc is not None:
+        res["traffic_source"] = pmc["source"] + (" (attached launch by launch)" if len(pmc["launches"]) == len(order) else
+                                                 " (NOT attached: the committed record has another launch sequence)")
+    return res
+
+
+def step_traffic(d):
+    """HBM bytes per launch of the training step from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, profiles/hbm_traffic.py --step-json), if the record is for this workload.  Not measured in this run:
+    counters need rocprofv3 around the process."""
+    for name in ("r03_step_hbm_traffic.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            if rec.get("dims") == [d.n_cons, d.n_vars, d.n_cuts, d.n_cons_edges, d.n_cut_edges]:
+                rec["source"] = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload (FETCH_SIZE doubled per MI355X_MICROARCH.md); not measured in this run"
+                return rec
+    return None
 
 
 def physical_cores():
@@ -232,9 +366,17 @@ def cpu_baseline(problem, batch_size, first_sample, budget_s=10.0):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus is not None and args.gpus > 1:   # no ranks exist yet: start them (before anything touches the GPU)
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif args.gpus is not None and args.gpus != int(os.environ["WORLD_SIZE"]):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to report a run of another size")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    _import_heavy()
+    if args.stub_worker:
+        return stub_worker(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     dev = torch.device("cuda", local_rank)
@@ -318,6 +460,10 @@ def main():
         blocks_dev.append(dev_ms)
         if sum(blocks_wall) >= args.min_seconds or len(blocks_wall) >= 1000:
             break
+    from gcnn_cut_selector_amd import _lib
+    with _lib.launch_profile() as prof:   # one more step on every rank, outside the timed region: how many launches a step is
+        train_step(model, batch, targets, opt, ts, process_group=group)
+    n_launches = len(prof.launches)
     edges_total = float(edges_local)
     rank_info = [{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
                   "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")), "edges_per_step": edges_local,
@@ -334,6 +480,10 @@ def main():
     if rank != 0:
         dist.destroy_process_group()
         return
+    if world_seen != world or (world > 1 and len({r["uuid"] or r["device"] for r in rank_info}) != world
+                               and os.environ.get("GCNN_ALLOW_SHARED_DEVICE") != "1"):
+        print(f"[bench] {world} ranks asked for, {world_seen} seen on devices {[r['uuid'] or r['device'] for r in rank_info]}", file=sys.stderr)
+        raise SystemExit(2)
     med = float(np.median(blocks_wall))
     ms_per_step = med / args.steps * 1e3
     local = [r["ms_per_step_local"] for r in rank_info]
@@ -351,7 +501,7 @@ def main():
                                 f"setcov-500 rows x global batch {args.batch} split over {world} GPU(s) by edge count")
                    if args.problem == "setcov" else f"{args.problem} x batch {args.batch} ({args.scaling} scaling)",
                    "step": "fwd + mse + bwd" + (" + rccl all-reduce(flat grads)" if group is not None else "") + " + adam",
-                   "launch": launch,
+                   "launch": launch, "library_launches_per_step": n_launches, "problem": args.problem, "batch_per_gpu" if args.scaling == "weak" else "global_batch_samples": args.batch,
                    "global_batch": args.batch * world if args.scaling == "weak" else args.batch, "edges_per_step": edges_total,
                    "n_cons": batch.dims.n_cons, "n_vars": batch.dims.n_vars, "n_cuts": batch.dims.n_cuts,
                    "parallelism": f"dp{world}", "final_loss": float(loss)},

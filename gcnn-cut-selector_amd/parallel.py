@@ -65,6 +65,30 @@ def allgather_prenorm(count, mean, var, received: bool, process_group, device):
     return c, m, v, any(r[0] != 0 for r in rows)
 
 
+def allgather_concat(t, process_group):
+    """Ragged all-gather along dim 0: every rank passes a tensor with its own number of rows (same trailing shape and dtype),
+    every rank gets the concatenation in rank order.  One small all-gather of the row counts, one of the tensors padded to the
+    longest (over RCCL the payload stays on the device; a gloo group moves it through host memory)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(process_group)
+    on_gpu = dist.get_backend(process_group) == "nccl"
+    dev = t.device
+    work = t if (on_gpu or not t.is_cuda) else t.cpu()
+    n = torch.tensor([work.shape[0]], dtype=torch.int64, device=work.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=process_group)
+    counts = [int(c) for c in counts]
+    longest = max(counts)
+    if longest == 0:
+        return t
+    padded = work.new_zeros((longest,) + tuple(work.shape[1:]))
+    padded[:work.shape[0]] = work
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded.contiguous(), group=process_group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(dev)
+
+
 def pack(grads: np.ndarray, n_cuts: int) -> np.ndarray:
     """[local gradient of the SUM of squared errors | local cut count | pad] -- the buffer that is all-reduced."""
     buf = np.zeros(grads.size + 4, np.float32)

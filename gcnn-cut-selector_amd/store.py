@@ -69,28 +69,52 @@ class SampleStore:
         return store._finalise()
 
     @classmethod
-    def from_files(cls, files, device=None, chunk=64, workers=8):
-        """Decode every file once (a pool of spawned processes: zlib + pickle hold the GIL; forking a process that has
-        initialised the GPU is not an option) and move the samples to the device.  As with any spawn pool the calling
-        script needs the usual `if __name__ == "__main__":` guard; `workers=0` decodes in-process."""
+    def from_files(cls, files, device=None, chunk=64, workers=8, process_group=None):
+        """Decode every file once and move the samples to the device.  The gunzip work runs in `workers` child processes that are
+        fresh, torch-free interpreters (`utils.decode_files`; `workers=0` decodes in-process); the calling script needs no
+        `if __name__ == "__main__":` guard.
+
+        Data parallel (`process_group` given; every rank passes the SAME file list): rank r decodes only the r-th contiguous share
+        of the files -- 1/N of the zlib work and of the host memory per rank instead of N processes re-decoding everything on one
+        host -- and the ranks then exchange their device arrays ONCE (one padded all-gather per array over RCCL / xGMI), so every
+        rank ends up holding the whole store, array for array identical to a single-process ingestion: `batches(ids, b, rank,
+        world)` keeps drawing any sample on any rank, as the reference's epoch sampling with replacement needs
+        (model_trainer.py:147), with shards balanced by edge count."""
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         store = cls(device)
         files = list(files)
-        if workers and len(files) > 1:
-            import multiprocessing as mp
-            with mp.get_context("spawn").Pool(min(workers, len(files))) as pool:
+        rank, world = 0, 1
+        if process_group is not None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        lo, hi = (len(files) * rank) // world, (len(files) * (rank + 1)) // world
+        pending = []
+        for sample in utils.decode_files(files[lo:hi], workers):
+            pending.append(sample)
+            if len(pending) == chunk:
+                store._add_chunk(pending)
                 pending = []
-                for sample in pool.imap(utils.load_sample, files, chunksize=4):
-                    pending.append(sample)
-                    if len(pending) == chunk:
-                        store._add_chunk(pending)
-                        pending = []
-                if pending:
-                    store._add_chunk(pending)
-        else:
-            for i in range(0, len(files), chunk):
-                store._add_chunk([utils.load_sample(f) for f in files[i:i + chunk]])
-        return store._finalise()
+        if pending:
+            store._add_chunk(pending)
+        store._finalise()
+        if world > 1:
+            store._exchange(process_group)
+        return store
+
+    def _exchange(self, process_group):
+        """After a sharded ingestion: every rank contributes its samples, every rank receives all of them, in rank order (= file
+        order).  All stored index values are sample-local, so concatenation is all it takes."""
+        from .parallel import allgather_concat
+        ag = lambda t: allgather_concat(t, process_group)
+        self.cons_feats, self.var_feats, self.cut_feats, self.improvements = (ag(t) for t in (
+            self.cons_feats, self.var_feats, self.cut_feats, self.improvements))
+        self.graphs = [{f: ag(g[f]) for f in _GRAPH_FIELDS} for g in self.graphs]
+        meta = torch.from_numpy(np.concatenate([self.sizes, np.stack([m for per_set in self.max_deg for m in per_set])]).T.copy())  # [n, 9]
+        meta = ag(meta.to(self.device)).cpu().numpy().T
+        self.sizes = np.ascontiguousarray(meta[:5])
+        self.max_deg = [[meta[5], meta[6]], [meta[7], meta[8]]]
+        self.offsets = np.concatenate([np.zeros((5, 1), np.int64), np.cumsum(self.sizes, axis=1)], axis=1)
+        self._jobs = None
 
     def _add_chunk(self, samples):
         if self._final:

@@ -30,6 +30,77 @@ def load_sample(path: str):
     return sample["data"]
 
 
+def decode_files(files, workers=8, prefetch=4):
+    """Yield `load_sample(f)` for every file, in order, with the gunzip work (~90 % of a load) spread over `workers` child
+    processes.  The children are fresh interpreters running `_decode_worker.py` by path -- standard library only: no torch, no
+    re-import of the caller's `__main__`, no `if __name__ == "__main__"` guard needed in the calling script -- fed file names over a
+    pipe and answering with the decompressed bytes, which are unpickled HERE with the NumPy-only unpickler.  They end on end of
+    input with exit code 0 (no signal is ever sent to a child that is still running normally).  `workers=0`: decode in-process."""
+    files = [str(f) for f in files]
+    if not workers or len(files) < 2:
+        for f in files:
+            yield load_sample(f)
+        return
+    import io
+    import os
+    import struct
+    import subprocess
+    import sys
+    n = min(int(workers), len(files))
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_decode_worker.py")
+    procs = [subprocess.Popen([sys.executable, "-S", "-E", script], stdin=subprocess.PIPE, stdout=subprocess.PIPE) for _ in range(n)]
+    try:   # a megabyte of pipe per child (Linux; the default is 64 KiB): a child can finish a sample while the parent reads another's
+        import fcntl
+        for p in procs:
+            fcntl.fcntl(p.stdout.fileno(), getattr(fcntl, "F_SETPIPE_SZ", 1031), 1 << 20)
+    except (ImportError, OSError):
+        pass
+    sent = [0] * n    # files handed to each child so far (child w serves files w, w + n, w + 2n, ...)
+
+    def feed(w):       # a few names ahead of what has been read back: the children never starve, the name pipe never fills
+        i = w + sent[w] * n
+        if i < len(files):
+            procs[w].stdin.write(files[i].encode("utf-8", "surrogateescape") + b"\n")
+            procs[w].stdin.flush()
+            sent[w] += 1
+        elif procs[w].stdin and not procs[w].stdin.closed:
+            procs[w].stdin.close()     # end of input: the child exits by itself
+
+    def read_exact(pipe, k):
+        buf = pipe.read(k)
+        if len(buf) != k:
+            raise RuntimeError("sample decoder child ended early")
+        return buf
+
+    ok = False
+    try:
+        for w in range(n):
+            for _ in range(prefetch):
+                feed(w)
+        for i, f in enumerate(files):
+            w = i % n
+            out = procs[w].stdout
+            (size,) = struct.unpack("<Q", read_exact(out, 8))
+            if size == 2 ** 64 - 1:
+                (k,) = struct.unpack("<Q", read_exact(out, 8))
+                raise OSError(f"{f}: {read_exact(out, k).decode('utf-8', 'replace')}")
+            sample = _safe_pickle.load(io.BytesIO(read_exact(out, size)))
+            feed(w)
+            yield sample["data"]
+        ok = True
+    finally:
+        for p in procs:                # normal end: stdin is closed already and the child is on its way out
+            if p.stdin and not p.stdin.closed:
+                p.stdin.close()
+            p.stdout.close()           # abnormal end (an exception above, an abandoned generator): the child sees a closed pipe
+        for p in procs:
+            try:
+                p.wait(timeout=30 if ok else 5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+
 def collate(samples):
     """The array half of `utils.load_batch` (utils.py:389-426) on already loaded (state, improvements) pairs."""
     cons = [s[0][0]["values"] for s in samples]

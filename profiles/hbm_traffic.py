@@ -2,12 +2,52 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected SEPARATELY, as
 MI355X_MICROARCH.md prescribes): python hbm_traffic.py <fetch counter_collection.csv> <write counter_collection.csv>
                                  python hbm_traffic.py <fetch csv> <write csv> --json "<kernel name prefix>"
+                                 python hbm_traffic.py <fetch csv> <write csv> --step-json C V K E1 E2
 Units: the counters are in KB; FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads).  --json prints the record
-bench.py attaches to its roofline block (traffic_bytes_per_launch of one kernel)."""
+bench.py attaches to its roofline block (traffic_bytes_per_launch of one kernel); --step-json prints the training step launch by
+launch (dispatches in order, a step = everything up to and including k_reduce; averaged position by position over the steps that
+have the most common launch sequence) -- what bench.py attaches to roofline_step as `traffic`."""
 import collections
 import csv
 import json
 import sys
+
+
+
+def step_records(path, name):
+    """[(kernel, [values per step])] in launch order, from one pass's counter_collection.csv."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == name]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    by_dispatch = collections.OrderedDict()   # a dispatch may appear on several rows (one per counter instance): sum them
+    for r in rows:
+        k = int(r["Dispatch_Id"])
+        by_dispatch.setdefault(k, [r["Kernel_Name"].split("(")[0].replace("void ", ""), 0.0])[1] += float(r["Counter_Value"])
+    steps, cur, live = [], [], False
+    for kern, val in by_dispatch.values():
+        if kern.startswith("k_embed_fwd"):
+            cur, live = [], True
+        if live:
+            cur.append((kern, val))
+            if kern.startswith("k_reduce"):
+                steps.append(cur)
+                live = False
+    if not steps:
+        return []
+    common = collections.Counter(tuple(k for k, _ in s) for s in steps).most_common(1)[0][0]
+    same = [s for s in steps if tuple(k for k, _ in s) == common]
+    return [(kern, [s[i][1] for s in same]) for i, kern in enumerate(common)]
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "--step-json":
+    fetch, write = step_records(sys.argv[1], "FETCH_SIZE"), step_records(sys.argv[2], "WRITE_SIZE")
+    assert [k for k, _ in fetch] == [k for k, _ in write], "the two passes saw different launch sequences"
+    launches = [{"kernel": k, "fetch_bytes": 2 * 1024 * sum(f) / len(f), "write_bytes": 1024 * sum(w) / len(w), "steps_averaged": len(f)}
+                for (k, f), (_, w) in zip(fetch, write)]
+    print(json.dumps({"dims": [int(x) for x in sys.argv[4:9]], "launches": launches,
+                      "traffic_bytes_per_step": sum(r["fetch_bytes"] + r["write_bytes"] for r in launches),
+                      "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                              "(gfx950 reports half of wide coalesced reads); counter units KB"}, indent=1))
+    sys.exit(0)
 
 res = collections.OrderedDict()
 for path, name in ((sys.argv[1], "FETCH_SIZE"), (sys.argv[2], "WRITE_SIZE")):

@@ -1,0 +1,129 @@
+"""Randomised parity sweep (GPU), seeded: random bipartite states around the sizes where the kernels change strategy -- C / V /
+K around 1, 15-17 (one 16-row tile), 255-257 (the four-waves-per-tile limit of 256 tiles is reached through K = 4095-4097),
+hub rows and hub variables (long segments next to short ones), duplicate entries (`tf.scatter_nd` sums them, model.py:568),
+unsorted COO lists (any order is accepted; `get_state` emits (row, col)-sorted ones, utils.py:102-104), isolated nodes.
+
+Per case, against the fp64 oracle (edge semantics: /root/reference/model.py:563-575):
+  * scores of `model(state)` and of the one-call inference path `score_state`: rtol = atol = 1e-4 (the north star's tolerance);
+  * all 46 gradients of the autograd path: 1e-4 of each tensor's largest entry, or three times the distance of torch's own fp32
+    evaluation of the restatement from fp64 where that is larger (cancellation in d w_edge).  A tensor beyond that bound passes only
+    under the single-column confinement rule: a ReLU pre-activation within rounding of zero may take the other branch in this
+    fp32 evaluation than in fp64, which moves ONE output column of one weight gradient by one row's share -- so all columns but
+    the worst must still be within the bound, and the worst within 5e-3;
+  * the fused training step (forward + MSE head + cut-row turnaround in one launch, backward from there) against the autograd
+    path: gradients rtol 1e-4, loss against the oracle;
+  * the ranking `score_state(rank=True)` returns against Python's `sorted(range(n), key=..., reverse=True)` (model_evaluator.py:110)
+    on the returned scores: exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gcnn_oracle as O  # noqa: E402  (checker only)
+
+# (C, V, K, max edges per node for E1, for E2, hubs, duplicates allowed, sorted like get_state)
+CASES = [
+    (1, 1, 1, 3, 2, False, True, True),
+    (2, 3, 1, 4, 4, False, True, False),
+    (15, 16, 17, 6, 5, True, False, True),
+    (16, 17, 15, 8, 8, False, True, False),
+    (17, 15, 16, 5, 9, True, True, True),
+    (100, 33, 31, 12, 10, True, False, True),
+    (255, 256, 32, 10, 12, False, False, True),
+    (256, 257, 255, 6, 6, True, True, False),
+    (257, 255, 256, 8, 4, False, False, True),
+    (1000, 500, 257, 20, 12, True, False, True),
+    (5000, 3, 2, 2, 3, True, True, False),
+    (1, 4097, 100, 50, 40, False, False, True),
+    (4095, 4096, 64, 3, 10, True, False, True),
+    (4096, 4097, 4095, 2, 3, False, True, False),
+    (4097, 4095, 4096, 3, 2, True, False, True),
+    (300, 9000, 4097, 8, 2, True, False, True),
+    (6000, 1200, 4200, 4, 3, False, False, False),
+    (16, 16, 16, 0, 0, False, False, True),         # no edges at all
+    (40, 60, 16, 10, 0, True, False, True),         # cuts without nonzeros
+    (33, 2000, 48, 60, 100, True, False, True),     # cut rows of ~100 nonzeros (the block-per-segment edge pass)
+    (500, 1000, 90, 50, 120, False, False, True),   # one setcov-like sample
+    (2, 5000, 1000, 4, 4, True, True, False),       # two constraint rows of thousands of entries
+    (1200, 700, 15, 3, 300, True, False, True),
+    (64, 64, 1024, 30, 30, True, True, False),
+]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    from test_gpu_model import _model
+    return _model(11, dev)
+
+
+def _state(case, rng):
+    C, V, K, d1, d2, hubs, dups, sorted_like_get_state = case
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+
+    def edge_list(n_left, n_e):
+        def ends(n):
+            a = rng.integers(0, n, n_e)
+            if hubs and n_e:       # a third of the entries land on a handful of hub nodes
+                a[: n_e // 3] = rng.integers(0, max(1, n // 50 + 1), n_e // 3)
+            return a
+        ei = np.stack([ends(n_left), ends(V)]).astype(np.int32)
+        if not dups and n_e:
+            ei = np.unique(ei, axis=1)
+            ei = ei[:, rng.permutation(ei.shape[1])]
+        if sorted_like_get_state and ei.shape[1]:
+            ei = ei[:, np.lexsort((ei[1], ei[0]))]
+        return ei
+
+    cei = edge_list(C, int(rng.integers(0, d1 * max(C, V) + 1)) if d1 else 0)
+    kei = edge_list(K, int(rng.integers(0, d2 * max(K, 8) + 1)) if d2 else 0)
+    return (f(C, 4), cei, f(cei.shape[1], 1), f(V, 14), f(K, 6), kei, f(kei.shape[1], 1), C, V, K)
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)))
+def test_random_state_parity(dev, model, idx):
+    from gcnn_cut_selector_amd.trainer import TrainState, train_step
+    m, params = model
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    rng = np.random.default_rng(1000 + idx)
+    state = _state(CASES[idx], rng)
+    K = state[9]
+    y = rng.uniform(0, 0.2, K)
+    # ---- scores: general path and the one-call inference path
+    want = O.scores(p64, state, torch.float64)
+    with torch.no_grad():
+        got = m(state, False).numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    q = m.score_state(state, rank=True)
+    np.testing.assert_allclose(q.numpy(), want, rtol=1e-4, atol=1e-4)
+    assert list(q.rankings) == sorted(range(K), key=lambda i: q[i], reverse=True)
+    # ---- all 46 gradients (autograd path)
+    pred = m(state, True)
+    loss = ((pred - torch.as_tensor(y, device=pred.device)) ** 2).mean()
+    m.flat_parameters.grad = None
+    loss.backward()
+    _, want_loss, wg = O.loss_and_grads(p64, state, y, torch.float64)
+    _, _, wg32 = O.loss_and_grads(params, state, y, torch.float32)
+    assert abs(float(loss.detach()) - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    for name, g in zip([n for n, _, t in O.PARAM_SPEC if t], m.gradients()):
+        g = g.cpu().numpy().astype(np.float64)
+        ref = max(np.abs(wg[name]).max(), 1e-6)
+        err = np.abs(g - wg[name]) / ref
+        bound = max(1e-4, 3 * np.abs(wg32[name].astype(np.float64) - wg[name]).max() / ref) + 1e-7
+        if err.max() > bound:      # single-column confinement: one flipped ReLU unit moves one output column, nothing wider
+            cols = err.reshape(-1, err.shape[-1]).max(0)
+            assert np.sort(cols)[-2] <= bound if cols.size > 1 else False, (name, float(err.max()), bound, np.sort(cols)[-4:])
+            assert err.max() <= 5e-3, (name, float(err.max()))
+    # ---- the fused training step against the autograd path
+    batch = m.prepare(state)
+    ts = TrainState(m)
+    loss2, _ = train_step(m, batch, torch.as_tensor(y, dtype=torch.float32).to(dev), None, ts)
+    ga, gf = m.flat_parameters.grad.cpu().numpy(), ts.grads.cpu().numpy()
+    np.testing.assert_allclose(gf, ga, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(ga).max())))
+    assert abs(float(loss2) - want_loss) <= 1e-4 * max(1.0, abs(want_loss))

@@ -234,3 +234,84 @@ def test_data_parallel_prenorm_fit_matches_single_process(tmp_path):
         assert float(r0["count"]) == len(allx) and bool(r0["received"])
         np.testing.assert_allclose(r0["mean"], allx.mean(0), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(r0["var"], allx.var(0), rtol=1e-4)
+
+
+def test_decode_files_children_are_torch_free_and_match_load_sample(tmp_path):
+    """`utils.decode_files`: gunzip in child interpreters that import the standard library only (no torch, no re-import of the
+    caller's __main__), results equal to `load_sample` file by file, errors raised in the parent, children gone afterwards."""
+    import subprocess
+    import sys
+    samples = [synthetic.make_sample("combauc", i) for i in range(7)]
+    files = []
+    for i, (state, imp) in enumerate(samples):
+        files.append(str(tmp_path / f"sample_{i}.pkl"))
+        utils.save_sample(files[-1], state, imp)
+    want = [utils.load_sample(f) for f in files]
+    for workers in (0, 1, 3, 16):
+        got = list(utils.decode_files(files, workers))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            for dg, dw in zip(g[0], w[0]):
+                assert dg["features"] == dw["features"] and all(np.array_equal(dg[k], dw[k]) for k in dw if k != "features")
+            assert np.array_equal(g[1], w[1])
+    with pytest.raises(OSError):
+        list(utils.decode_files(files[:2] + [str(tmp_path / "missing.pkl")] + files[2:], 2))
+    worker = os.path.join(ROOT, "gcnn-cut-selector_amd", "_decode_worker.py")
+    probe = ("import sys, runpy; sys.argv = ['w']; sys.stdin = open('/dev/null'); runpy.run_path(%r, run_name='__main__'); "
+             "print(int(any(m == 'torch' or m == 'numpy' or m.startswith('gcnn') for m in sys.modules)))" % worker)
+    out = subprocess.run([sys.executable, "-S", "-E", "-c", probe], capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == "0"
+
+
+def _gather_worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    rows = [5, 0][rank] if world == 2 else rank
+    a = torch.from_numpy(rng.standard_normal((rows, 14)).astype(np.float32))
+    b = torch.from_numpy(rng.integers(0, 1000, 3 + 2 * rank).astype(np.int32))
+    e = torch.zeros(0, 4)                                       # nobody holds a row
+    out = [parallel.allgather_concat(t, dist.group.WORLD) for t in (a, b, e)]
+    np.savez(os.path.join(tmpdir, f"ag_{rank}.npz"), a=out[0].numpy(), b=out[1].numpy(), e=out[2].numpy(), mine_a=a.numpy(), mine_b=b.numpy())
+    dist.destroy_process_group()
+
+
+def test_allgather_concat_is_a_rank_ordered_ragged_concatenation(tmp_path):
+    """The exchange step of a sharded `SampleStore.from_files` (world_size 2 over gloo): ranks hold different row counts (one of
+    them none); every rank gets the rank-ordered concatenation, dtype and trailing shape kept."""
+    import torch.multiprocessing as mp
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), f"ag_{r}.npz")) for r in range(2))
+    for k in ("a", "b"):
+        want = np.concatenate([r0["mine_" + k], r1["mine_" + k]])
+        assert r0[k].dtype == want.dtype and np.array_equal(r0[k], want) and np.array_equal(r1[k], want)
+    assert r0["e"].shape == (0, 4) and r1["e"].shape == (0, 4)
+
+
+def test_bench_gpus_n_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` without WORLD_SIZE must start two ranks (fresh children with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set), relay rank 0's line and fail when a rank fails or the line does not show 2 ranks on 2 devices.  Run here with
+    the stub worker (gloo on CPU, no GPU work); the launcher code is the one a GPU run uses."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = lambda extra, **kw: subprocess.run([sys.executable, bench, "--gpus", "2", "--stub-worker"], capture_output=True, text=True,
+                                             env=dict(env, **extra), timeout=300, **kw)
+    ok = run({})
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [ln for ln in ok.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                                  # ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["world_size_observed"] == 2
+    assert sorted(r["rank"] for r in out["distributed"]["ranks"]) == [0, 1]
+    assert len({r["uuid"] for r in out["distributed"]["ranks"]}) == 2
+    failed = run({"GCNN_BENCH_STUB_FAIL": "1"})                             # a rank dies: non-zero, no line
+    assert failed.returncode != 0 and not failed.stdout.strip()
+    shared = run({"GCNN_BENCH_STUB_SAME_DEVICE": "1"})                      # two ranks on one device: refused
+    assert shared.returncode != 0 and not shared.stdout.strip()
+    wrong = run({"WORLD_SIZE": "1", "RANK": "0"})                           # ranks exist but not as many as --gpus says
+    assert wrong.returncode != 0 and not wrong.stdout.strip()
