@@ -53,14 +53,21 @@ static int device_cus() {   // compute units of the current device (MI355X: 256)
 // one thread; off by default and then a single predictable branch per launch.
 #define GCNN_PROF_MAX 512
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
-static struct { bool on; int n; ProfRec rec[GCNN_PROF_MAX]; } g_prof;
+// `dev`: the device the cached events belong to (events are per device; gcnn_profile_begin drops them when the current device
+// is another one).  One profiling session at a time, on one device.
+static struct { bool on; int n; int dev; ProfRec rec[GCNN_PROF_MAX]; } g_prof;
 struct ProfScope {
     hipStream_t st; bool live;
     ProfScope(const char* name, hipStream_t s) : st(s), live(g_prof.on && g_prof.n < GCNN_PROF_MAX) {
         if (!live) return;
         ProfRec& r = g_prof.rec[g_prof.n];
         r.name = name;
-        if (!r.e0 && (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess)) { live = false; return; }
+        if (!r.e0) {   // both events or none: a half-made pair would be reused for ever
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess) { live = false; return; }
+            if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); live = false; return; }
+            r.e0 = a; r.e1 = b;
+        }
         (void)hipEventRecord(r.e0, st);
     }
     ~ProfScope() { if (live) { (void)hipEventRecord(g_prof.rec[g_prof.n].e1, st); ++g_prof.n; } }
@@ -247,7 +254,17 @@ extern "C" {
 
 int gcnn_abi_version(void) { return 9; }
 
-int gcnn_profile_begin(void) { g_prof.n = 0; g_prof.on = true; return 0; }
+int gcnn_profile_begin(void) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return GCNN_E_HIP;
+    if (d != g_prof.dev)   // the cached events were made on another device: they cannot be recorded on this one's streams
+        for (ProfRec& r : g_prof.rec) {
+            if (r.e0) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+            r.e0 = r.e1 = nullptr;
+        }
+    g_prof.dev = d; g_prof.n = 0; g_prof.on = true;
+    return 0;
+}
 int gcnn_profile_end(int32_t capacity, const char** names, float* ms) {
     g_prof.on = false;
     const int n = g_prof.n;
@@ -827,10 +844,10 @@ static void add_wg_emb1(JobList& jl, const float* x, const float* shift, const f
     jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f};
 }
 // Order the collected jobs and give them their block ranges.  Several jobs read the same matrix (dZ1 feeds the gradients of
-// both halves of W1; a raw embedding X is the operand of up to three products): such jobs are placed next to each other,
-// and every job starts at a block index that is a multiple of 8, so the blocks of two adjacent jobs that read the same rows
-// run on the same XCD (blocks are dealt to the eight XCDs round-robin) at about the same time -- the second read hits that
-// XCD's L2 instead of going to memory.  Padding blocks own no rows and exit at once.  Values do not depend on the order.
+// both halves of W1; a raw embedding X is the operand of up to three products): such jobs are placed next to each other and
+// k_wgrad rotates each job's block -> row-block mapping so that (row block) = (block index) mod 8: blocks are dealt to the eight
+// XCDs round-robin, so the same rows of two adjacent jobs are read on the same XCD at about the same time and the second read
+// hits that XCD's L2 instead of going to memory.  Values do not depend on the order.
 static void place_wg(JobList& jl, float* partial) {
     bool used[WG_MAX_JOBS] = {};
     int order[WG_MAX_JOBS], last = -1;
@@ -847,12 +864,13 @@ static void place_wg(JobList& jl, float* partial) {
     // Chunk size: the launch is ONE resident round -- two blocks (8 waves) per CU, every SIMD holding two waves of (nearly) the
     // same length from start to end, so the MFMA pipes stay shared evenly and there is no second, partly filled round.
     // Smallest chunk (a multiple of 16 rows, at least WG_ROWS) whose block count fits; each job then spreads its rows evenly.
-    const int slots = std::min(2 * device_cus(), WG_MAX_SLABS - WG_MAX_JOBS);
+    // (every job needs at least one block, so fewer slots than jobs -- a device with a handful of CUs -- can never be met)
+    const int slots = std::max(std::min(2 * device_cus(), WG_MAX_SLABS - WG_MAX_JOBS), jl.npend);
     auto blocks_at = [&](int r) { long long t = 0; for (int k = 0; k < jl.npend; ++k) t += cdiv(jl.pend[k].n, r * WG_WAVES); return t; };
     int rows = WG_ROWS;
     if (blocks_at(rows) > slots) {   // bisect on multiples of 16
         int lo = rows / 16, hi = lo;
-        while (blocks_at(hi * 16) > slots) hi *= 2;
+        while (blocks_at(hi * 16) > slots && hi < (1 << 24)) hi *= 2;
         while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (blocks_at(mid * 16) > slots) lo = mid; else hi = mid; }
         rows = hi * 16;
     }

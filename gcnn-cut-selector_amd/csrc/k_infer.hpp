@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void k_rank_scores(const float* __restrict__ s
     __shared__ int ix[4096];
     int m = 1;
     while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 256) { v[i] = i < n ? scores[i] : -INFINITY; ix[i] = i < n ? i : 0x7fffffff; }
+    for (int i = threadIdx.x; i < m; i += 256) {
+        const float x = i < n ? scores[i] : -INFINITY;
+        v[i] = x != x ? -INFINITY : x; ix[i] = i < n ? i : 0x7fffffff;
+    }
     __syncthreads();
     for (int k = 2; k <= m; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {

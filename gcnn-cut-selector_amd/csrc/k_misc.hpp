@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void k_ranking(const float* __restrict__ pred,
     while (m < n) m <<= 1;
     for (int i = threadIdx.x; i < m; i += 256) {
         const bool in = i < n;
-        v[0][i] = in ? pred[beg + i] : -INFINITY; v[1][i] = in ? truth[beg + i] : -INFINITY;
+        const float a = in ? pred[beg + i] : -INFINITY, b = in ? truth[beg + i] : -INFINITY;
+        v[0][i] = a != a ? -INFINITY : a; v[1][i] = b != b ? -INFINITY : b;   // NaN ranks as -inf: both lists stay permutations
         ix[0][i] = ix[1][i] = in ? i : 0x7fffffff;   // padding sorts last in both lists
     }
     if (threadIdx.x == 0) first_dev = n;

@@ -22,6 +22,42 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(0)
 
 
+class _MaxDegreeMailbox:
+    """Longest segment of a freshly built plan without a host wait: the two maxima are reduced on the device, copied into a
+    pinned slot behind the build, and picked up the first time the graph is used AFTER the copy has landed (until then the plan
+    says "unknown", which only means the long-segment finder launch always runs).  A small ring of slots; a slot taken over by a
+    newer graph before its owner looked simply leaves that owner at "unknown"."""
+    SLOTS = 32
+
+    def __init__(self):
+        self.host, self.events, self.gen, self.pos = None, [None] * self.SLOTS, [0] * self.SLOTS, 0
+
+    def post(self, values_dev):
+        if self.host is None:
+            self.host = torch.zeros(self.SLOTS, 2, dtype=torch.int32).pin_memory()
+        i = self.pos
+        self.pos = (i + 1) % self.SLOTS
+        self.gen[i] += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()      # an older copy into this slot (32 graphs ago) must have landed before the next one starts
+        self.host[i].copy_(values_dev, non_blocking=True)
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record(torch.cuda.current_stream(values_dev.device))
+        return i, self.gen[i]
+
+    def poll(self, ticket):
+        """(l_max_deg, v_max_deg) once the copy is done, None while it is in flight, False if the slot was taken over."""
+        i, gen = ticket
+        if self.gen[i] != gen:
+            return False
+        if not self.events[i].query():
+            return None
+        return tuple(int(x) for x in self.host[i].tolist())
+
+
+_mailbox = _MaxDegreeMailbox()
+
+
 class BipartiteGraph:
     """One edge set (constraint<->variable or cut<->variable) in by-left and by-variable CSR form, on the GPU.
 
@@ -29,7 +65,7 @@ class BipartiteGraph:
     edge_feats: [E,1] or [E] fp32 raw coefficients.  Any edge order is accepted; ties keep input order."""
 
     def __init__(self, edge_inds: torch.Tensor, edge_feats: torch.Tensor, n_left: int, n_var: int, validate=True,
-                 keep_perm=False):
+                 keep_perm=False, sync_max_degree=False):
         if edge_inds.dim() != 2 or edge_inds.shape[0] != 2:
             raise ValueError(f"edge index tensor must have shape [2,E], got {tuple(edge_inds.shape)}")
         if edge_inds.dtype != torch.int32:
@@ -73,13 +109,19 @@ class BipartiteGraph:
                                             temp_bytes, _stream(dev)), "gcnn_graph_build")
         # keep the temp alive until the stream has consumed it
         temp.record_stream(torch.cuda.current_stream(dev))
-        # longest segment of either order (one small read-back; building a plan is not on the timed path): lets the edge passes
-        # skip their long-segment launch when the list has no segment that is long for its mean degree
+        # longest segment of either order: lets the edge passes skip their long-segment launch when the list has no segment
+        # that is long for its mean degree.  Not waited for (`sync_max_degree=False`, the default: GCNN.prepare stays free of host
+        # synchronisation beyond the optional validation read): the values arrive through a pinned mailbox and are adopted by
+        # the first use after the copy has landed; 0 = unknown until then.
         self.l_max_deg = self.v_max_deg = 0
+        self._md_ticket = None
         if n_edges > 0:
             md = torch.stack([(self.l_ptr[1:] - self.l_ptr[:-1]).max() if n_left else self.l_ptr.new_zeros(()),
-                              (self.v_ptr[1:] - self.v_ptr[:-1]).max() if n_var else self.v_ptr.new_zeros(())]).tolist()
-            self.l_max_deg, self.v_max_deg = int(md[0]), int(md[1])
+                              (self.v_ptr[1:] - self.v_ptr[:-1]).max() if n_var else self.v_ptr.new_zeros(())])
+            if sync_max_degree:
+                self.l_max_deg, self.v_max_deg = (int(x) for x in md.tolist())
+            else:
+                self._md_ticket = _mailbox.post(md)
         self._bind()
 
     @classmethod
@@ -91,12 +133,25 @@ class BipartiteGraph:
         g.l_ptr, g.l_oth, g.l_coef, g.v_ptr, g.v_oth, g.v_coef = l_ptr, l_oth, l_coef, v_ptr, v_oth, v_coef
         g.l_perm = None
         g.l_max_deg, g.v_max_deg = int(l_max_deg), int(v_max_deg)
+        g._md_ticket = None
         g._bind()
         return g
 
+    @property
+    def c(self):
+        """The `gcnn_graph` struct the C ABI takes; adopts the longest-segment values once their copy has landed."""
+        if self._md_ticket is not None:
+            got = _mailbox.poll(self._md_ticket)
+            if got is not None:
+                self._md_ticket = None
+                if got:
+                    self.l_max_deg, self.v_max_deg = got
+                    self._bind()
+        return self._c
+
     def _bind(self):
         n_edges = self.n_edges
-        self.c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
+        self._c = _lib.Graph(self.l_ptr.data_ptr(), self.l_oth.data_ptr() if n_edges else 0,
                             self.l_coef.data_ptr() if n_edges else 0, self.v_ptr.data_ptr(),
                             self.v_oth.data_ptr() if n_edges else 0, self.v_coef.data_ptr() if n_edges else 0,
                             self.l_max_deg, self.v_max_deg)

@@ -102,8 +102,8 @@ class _InferenceSession:
             else:
                 _lib.check(rc, "gcnn_infer_layout_for")
                 lay = (dims, lay, list(lay.in_off), list(lay.out_off))
-            if len(self.layouts) > 256:
-                self.layouts.clear()
+            if len(self.layouts) >= 256:
+                self.layouts.pop(next(iter(self.layouts)))   # evict the oldest entry only
             self.layouts[key] = lay
         return lay
 
@@ -125,6 +125,11 @@ class _InferenceSession:
                 raise ValueError(f"{name} must be an integer array of shape [2,E], got {ei.dtype} {tuple(ei.shape)}")
             if ef.size != ei.shape[1]:
                 raise ValueError("edge features must hold one value per edge")
+            # the upload packs indices as int32 with an unchecked cast: an int64 / uint index of 2**31 or more would wrap, possibly
+            # into range, and score another graph -- such lists are rejected here (int32 input cannot overflow; the device
+            # flags catch everything that is out of range but representable)
+            if ei.dtype != np.int32 and ei.size and (int(ei.max()) > 2 ** 31 - 1 or int(ei.min()) < -2 ** 31):
+                raise ValueError("edge index out of range (left ids must be in [0,n_left), variable ids in [0,n_vars))")
         key = (c.shape[0], v.shape[0], k.shape[0], cei.shape[1], kei.shape[1])
         lay = self._layout(key)
         if lay is False or (want_order and key[2] > 4096):

@@ -129,8 +129,8 @@ class SampleStore:
             if t.ndim != 2 or t.shape[1] != f:
                 raise ValueError(f"{name} must have shape [N,{f}], got {tuple(t.shape)}")
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        g1 = BipartiteGraph(up(cei), up(cef), c.shape[0], v.shape[0], validate=True)   # raises on out-of-range ids
-        g2 = BipartiteGraph(up(kei), up(kef), k.shape[0], v.shape[0], validate=True)
+        g1 = BipartiteGraph(up(cei), up(cef), c.shape[0], v.shape[0], validate=True, sync_max_degree=True)   # raises on out-of-range ids
+        g2 = BipartiteGraph(up(kei), up(kef), k.shape[0], v.shape[0], validate=True, sync_max_degree=True)
         for name, a in (("cons_feats", c), ("var_feats", v), ("cut_feats", k), ("improvements", imp)):
             self._parts[name].append(up(a))
         for slot, (g, nl, ne) in enumerate(((g1, n_cons, n_e1), (g2, n_cuts, n_e2))):

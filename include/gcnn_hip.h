@@ -38,7 +38,8 @@ int gcnn_param_info(int index, int* offset, int* rows, int* cols, int* trainable
  * Between gcnn_profile_begin() and gcnn_profile_end() every kernel launch the library makes is bracketed by two HIP events
  * on its stream.  gcnn_profile_end waits for those events (the ONE entry point that synchronises), stores up to `capacity`
  * kernel names (static strings) and durations in milliseconds, launch by launch, and returns the number of launches seen
- * (possibly > capacity; at most 512 are recorded), or GCNN_E_HIP.  Single-threaded use only. */
+ * (possibly > capacity; at most 512 are recorded), or GCNN_E_HIP.  Single-threaded use only, one session at a time, all launches of
+ * a session on streams of the device that was current at gcnn_profile_begin (events are per device). */
 int gcnn_profile_begin(void);
 int gcnn_profile_end(int32_t capacity, const char** names /* host, optional */, float* ms /* host, optional */);
 

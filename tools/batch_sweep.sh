@@ -6,6 +6,6 @@ cd $GRAFT_REPO_ROOT
 O=${1:-gpurun_out/batch_sweep.jsonl}; mkdir -p $(dirname $O); : > $O
 for cfg in "setcov 4" "setcov 8" "setcov 16" "setcov 32" "setcov 64" "setcov 128" "capfac 4" "indset 8" "combauc 32" "capfac 32" "indset 64"; do
   set -- $cfg
-  python bench.py --problem $1 --batch $2 --no-cpu-baseline --no-roofline --sweep-line >> $O 2>> ${O%.jsonl}.err
+  python bench.py --problem $1 --batch $2 --no-cpu-baseline --no-roofline >> $O 2>> ${O%.jsonl}.err
   echo "$cfg done"
 done
