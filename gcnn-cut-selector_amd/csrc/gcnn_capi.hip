@@ -696,6 +696,8 @@ static int check_common(const gcnn_dims* d, const float* params, const gcnn_grap
     if (d->n_cons < 0 || d->n_vars < 0 || d->n_cuts < 0 || d->n_cons_edges < 0 || d->n_cut_edges < 0) return GCNN_E_BADARG;
     if (!workspace || workspace_floats < gcnn_workspace_floats(d)) return GCNN_E_WORKSPACE;
     if (((uintptr_t)workspace & 15) || ((uintptr_t)params & 15)) return GCNN_E_BADARG;
+    // the edge passes address a gathered table as base + 32-bit byte offset (row index << 8)
+    if (d->n_cons > (1 << 24) || d->n_vars > (1 << 24) || d->n_cuts > (1 << 24)) return GCNN_E_UNSUPPORTED;
     return 0;
 }
 

@@ -24,7 +24,7 @@
 #define SEG_U 16    // rows per lane group in flight in the standalone scatter-sum pass (k_seg_sum); 4 / 8 / 16 measured: 5.52 / 5.60 / 5.80 TB/s
 #endif
 #ifndef EDGE_UB
-#define EDGE_UB 4   // ... sender-ordered backward pass (two gathers per edge)
+#define EDGE_UB 2   // ... sender-ordered backward pass (two gathers per edge).  4 needs 100 VGPRs (four waves per SIMD): 23.7 vs 22.3 us per 800 k-edge pass
 #endif
 struct EdgeArgs {
     const int* seg_ptr; const int* oth; const float* coef;
@@ -69,27 +69,62 @@ struct EdgeLane {   // lane geometry of a G = 16*SLOTS lane group
 // receiver.  J_e = (c_e*w + P_oth[oth_e]) + P_own[r].  COUNT also emits N (training; inference skips it).
 // One segment [beg, end) of receiver r by one lane group (every lane of the group must call).
 struct EdgeSum { float4 acc, cnt; };   // per lane group, after the slot reduction: sum_e max/min(J_e, 0) and the active-edge counts
+// Row gathers address the table as base (uniform) + 32-bit byte offset, the offset (index << 8) made ONCE per loaded edge before it
+// is broadcast, and a segment runs in FULL steps (EDGE_U * SLOTS edges, no lane masks, all gathers issued back to back) followed by
+// at most one masked step: per gathered row that leaves one add of address arithmetic where 64-bit shifts, per-step bounds
+// compares and exec-mask branches used to be (-25 % vector instructions per edge; tables are limited to 2^24 rows).
+__device__ __forceinline__ float4 edge_row(const float* __restrict__ tab, unsigned byte_off) {
+    return *(const float4*)((const char*)tab + byte_off);
+}
+template <bool COUNT, bool NEG>
+__device__ __forceinline__ void edge_fwd_term(const float c, const float4 p, const float4 w, const float4 pown, float4& acc, unsigned (&n)[4]) {
+    float h0 = fmaf(c, w.x, p.x) + pown.x, h1 = fmaf(c, w.y, p.y) + pown.y;
+    float h2 = fmaf(c, w.z, p.z) + pown.z, h3 = fmaf(c, w.w, p.w) + pown.w;
+    h0 = NEG ? fminf(h0, 0.f) : fmaxf(h0, 0.f); h1 = NEG ? fminf(h1, 0.f) : fmaxf(h1, 0.f);
+    h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
+    acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
+    if (COUNT) {   // after the clamp "active" is "non-zero" (h = +-0 when clamped)
+        n[0] += h0 != 0.f; n[1] += h1 != 0.f; n[2] += h2 != 0.f; n[3] += h3 != 0.f;
+    }
+}
 template <int SLOTS, bool COUNT, bool NEG>
 __device__ __forceinline__ EdgeSum edge_fwd_partial(const EdgeArgs& a, const EdgeLane<SLOTS>& L, const float4 w, const float esh,
                                                     const float esc, const int r, const int beg, const int end) {
-    constexpr int G = 16 * SLOTS;
-    const int gl = L.gl, gbase = L.gbase, slot = L.slot, ch = L.ch;
+    constexpr int G = 16 * SLOTS, STEP = EDGE_U * SLOTS;
+    const int gl = L.gl, slot = L.slot, ch = L.ch;
     const float4 pown = *(const float4*)(a.p_own + (size_t)r * EMB + ch);
+    const unsigned chb = 4u * ch;                       // this lane's column, in bytes
+    const int src0 = (L.gbase + slot) << 2;             // ds_bpermute address of the lane holding edge `slot` of the chunk
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+    unsigned n[4] = {0, 0, 0, 0};
     for (int base = beg; base < end; base += G) {
         const int e = base + gl;
-        int o = 0; float c = 0.f;
-        if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
+        unsigned ob = 0; float c = 0.f;
+        if (e < end) { ob = (unsigned)a.oth[e] << 8; c = (a.coef[e] + esh) * esc; }   // row offset in bytes, PreNorm'ed coefficient
         const int cnt = min(G, end - base);
-        for (int i0 = 0; i0 < cnt; i0 += EDGE_U * SLOTS) {
-            int oi[EDGE_U]; float ci[EDGE_U]; bool ok[EDGE_U]; float4 p[EDGE_U];
+        int i0 = 0;
+        for (; i0 + STEP <= cnt; i0 += STEP) {   // full steps
+            unsigned oi[EDGE_U]; float ci[EDGE_U]; float4 p[EDGE_U];
+#pragma unroll
+            for (int u = 0; u < EDGE_U; ++u) {
+                const int src = src0 + ((i0 + u * SLOTS) << 2);
+                oi[u] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)ob);
+                ci[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c)));
+            }
+#pragma unroll
+            for (int u = 0; u < EDGE_U; ++u) p[u] = edge_row(a.p_oth, oi[u] + chb);
+#pragma unroll
+            for (int u = 0; u < EDGE_U; ++u) edge_fwd_term<COUNT, NEG>(ci[u], p[u], w, pown, acc, n);
+        }
+        if (i0 < cnt) {   // the rest of the chunk: fewer than STEP edges, slots past the end are masked
+            unsigned oi[EDGE_U]; float ci[EDGE_U]; bool ok[EDGE_U]; float4 p[EDGE_U];
 #pragma unroll
             for (int u = 0; u < EDGE_U; ++u) {
                 const int i = i0 + u * SLOTS + slot;
                 ok[u] = i < cnt;
-                const int src = gbase + (ok[u] ? i : 0);
-                oi[u] = __shfl(o, src); ci[u] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
+                const int src = ok[u] ? src0 + ((i0 + u * SLOTS) << 2) : (L.gbase << 2);   // by every lane: a shuffle must not sit under a lane mask
+                oi[u] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)ob);
+                ci[u] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c)));
             }
             // Wide lane groups (mean degree >= 12): unconditional gathers -- a slot past the end re-reads the row of the
             // group's first edge, unused -- because loads under a lane mask hide from the compiler how many are in flight.
@@ -97,25 +132,15 @@ __device__ __forceinline__ EdgeSum edge_fwd_partial(const EdgeArgs& a, const Edg
             // wasted gathers cost more than the waits (capfac x 32: +2 % per step when unconditional).
 #pragma unroll
             for (int u = 0; u < EDGE_U; ++u)
-                if (SLOTS > 1 || ok[u]) p[u] = *(const float4*)(a.p_oth + (size_t)oi[u] * EMB + ch);
+                if (SLOTS > 1 || ok[u]) p[u] = edge_row(a.p_oth, oi[u] + chb);
 #pragma unroll
-            for (int u = 0; u < EDGE_U; ++u) {
-                if (ok[u]) {
-                    float h0 = fmaf(ci[u], w.x, p[u].x) + pown.x, h1 = fmaf(ci[u], w.y, p[u].y) + pown.y;
-                    float h2 = fmaf(ci[u], w.z, p[u].z) + pown.z, h3 = fmaf(ci[u], w.w, p[u].w) + pown.w;
-                    h0 = NEG ? fminf(h0, 0.f) : fmaxf(h0, 0.f); h1 = NEG ? fminf(h1, 0.f) : fmaxf(h1, 0.f);
-                    h2 = NEG ? fminf(h2, 0.f) : fmaxf(h2, 0.f); h3 = NEG ? fminf(h3, 0.f) : fmaxf(h3, 0.f);
-                    acc.x += h0; acc.y += h1; acc.z += h2; acc.w += h3;
-                    if (COUNT) {   // after the clamp "active" is "non-zero" (h = +-0 when clamped)
-                        n0 += h0 != 0.f; n1 += h1 != 0.f; n2 += h2 != 0.f; n3 += h3 != 0.f;
-                    }
-                }
-            }
+            for (int u = 0; u < EDGE_U; ++u)
+                if (ok[u]) edge_fwd_term<COUNT, NEG>(ci[u], p[u], w, pown, acc, n);
         }
     }
     EdgeSum out;
     out.acc = slot_reduce<SLOTS>(acc);
-    out.cnt = COUNT ? slot_reduce<SLOTS>(make_float4((float)n0, (float)n1, (float)n2, (float)n3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    out.cnt = COUNT ? slot_reduce<SLOTS>(make_float4((float)n[0], (float)n[1], (float)n[2], (float)n[3])) : make_float4(0.f, 0.f, 0.f, 0.f);
     return out;
 }
 template <int SLOTS, bool COUNT, bool NEG>
@@ -225,43 +250,59 @@ __global__ __launch_bounds__(256) void k_edge_bwd_recv(const float* __restrict__
 //   dP_send[u] = s1 * sum_{e in seg(u)} t_e          d w_edge = s1 * sum_e c_e * t_e   (per-block partials, see edge_dw_block_store)
 // two 256-B row gathers per edge (dS and P_recv, same row index), nothing else.
 // Returns the segment's share of d w_edge (before the s1 factor), the same value in every lane of the group.
+template <bool NEG>
+__device__ __forceinline__ void edge_bwd_term(const float c, const float4 d, const float4 q, const float4 w, const float4 psend, float4& acc, float4& dw) {
+    const float j0 = fmaf(c, w.x, psend.x) + q.x, j1 = fmaf(c, w.y, psend.y) + q.y;
+    const float j2 = fmaf(c, w.z, psend.z) + q.z, j3 = fmaf(c, w.w, psend.w) + q.w;
+    const float t0 = (NEG ? j0 < 0.f : j0 > 0.f) ? d.x : 0.f, t1 = (NEG ? j1 < 0.f : j1 > 0.f) ? d.y : 0.f;
+    const float t2 = (NEG ? j2 < 0.f : j2 > 0.f) ? d.z : 0.f, t3 = (NEG ? j3 < 0.f : j3 > 0.f) ? d.w : 0.f;
+    acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
+    dw.x = fmaf(c, t0, dw.x); dw.y = fmaf(c, t1, dw.y); dw.z = fmaf(c, t2, dw.z); dw.w = fmaf(c, t3, dw.w);
+}
 template <int SLOTS, bool NEG>
 __device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
                                                         const float esh, const float esc, const int u, const int beg, const int end) {
-    constexpr int G = 16 * SLOTS;
-    const int gl = L.gl, gbase = L.gbase, slot = L.slot, ch = L.ch;
+    constexpr int G = 16 * SLOTS, STEP = EDGE_UB * SLOTS;
+    const int gl = L.gl, slot = L.slot, ch = L.ch;
     const float4 psend = *(const float4*)(a.p_own + (size_t)u * EMB + ch);
+    const unsigned chb = 4u * ch;
+    const int src0 = (L.gbase + slot) << 2;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), dw = acc;
     for (int base = beg; base < end; base += G) {
         const int e = base + gl;
-        int o = 0; float c = 0.f;
-        if (e < end) { o = a.oth[e]; c = (a.coef[e] + esh) * esc; }
+        unsigned ob = 0; float c = 0.f;
+        if (e < end) { ob = (unsigned)a.oth[e] << 8; c = (a.coef[e] + esh) * esc; }
         const int cnt = min(G, end - base);
-        for (int i0 = 0; i0 < cnt; i0 += EDGE_UB * SLOTS) {
-            int oi[EDGE_UB]; float ci[EDGE_UB]; bool ok[EDGE_UB]; float4 d[EDGE_UB], q[EDGE_UB];
+        int i0 = 0;
+        for (; i0 + STEP <= cnt; i0 += STEP) {   // full steps (see edge_fwd_partial)
+            unsigned oi[EDGE_UB]; float ci[EDGE_UB]; float4 d[EDGE_UB], q[EDGE_UB];
+#pragma unroll
+            for (int v = 0; v < EDGE_UB; ++v) {
+                const int src = src0 + ((i0 + v * SLOTS) << 2);
+                oi[v] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)ob);
+                ci[v] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c)));
+            }
+#pragma unroll
+            for (int v = 0; v < EDGE_UB; ++v) { d[v] = edge_row(a.d_s, oi[v] + chb); q[v] = edge_row(a.p_oth, oi[v] + chb); }
+#pragma unroll
+            for (int v = 0; v < EDGE_UB; ++v) edge_bwd_term<NEG>(ci[v], d[v], q[v], w, psend, acc, dw);
+        }
+        if (i0 < cnt) {
+            unsigned oi[EDGE_UB]; float ci[EDGE_UB]; bool ok[EDGE_UB]; float4 d[EDGE_UB], q[EDGE_UB];
 #pragma unroll
             for (int v = 0; v < EDGE_UB; ++v) {
                 const int i = i0 + v * SLOTS + slot;
                 ok[v] = i < cnt;
-                const int src = gbase + (ok[v] ? i : 0);
-                oi[v] = __shfl(o, src); ci[v] = __shfl(c, src);   // by every lane: a shuffle must not sit under a lane mask
+                const int src = ok[v] ? src0 + ((i0 + v * SLOTS) << 2) : (L.gbase << 2);   // by every lane: a shuffle must not sit under a lane mask
+                oi[v] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)ob);
+                ci[v] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c)));
             }
 #pragma unroll
             for (int v = 0; v < EDGE_UB; ++v)   // unconditional for wide lane groups, see edge_fwd_partial
-                if (SLOTS > 1 || ok[v]) {
-                    d[v] = *(const float4*)(a.d_s + (size_t)oi[v] * EMB + ch);
-                    q[v] = *(const float4*)(a.p_oth + (size_t)oi[v] * EMB + ch);
-                }
+                if (SLOTS > 1 || ok[v]) { d[v] = edge_row(a.d_s, oi[v] + chb); q[v] = edge_row(a.p_oth, oi[v] + chb); }
 #pragma unroll
             for (int v = 0; v < EDGE_UB; ++v)
-                if (ok[v]) {
-                    const float j0 = fmaf(ci[v], w.x, psend.x) + q[v].x, j1 = fmaf(ci[v], w.y, psend.y) + q[v].y;
-                    const float j2 = fmaf(ci[v], w.z, psend.z) + q[v].z, j3 = fmaf(ci[v], w.w, psend.w) + q[v].w;
-                    const float t0 = (NEG ? j0 < 0.f : j0 > 0.f) ? d[v].x : 0.f, t1 = (NEG ? j1 < 0.f : j1 > 0.f) ? d[v].y : 0.f;
-                    const float t2 = (NEG ? j2 < 0.f : j2 > 0.f) ? d[v].z : 0.f, t3 = (NEG ? j3 < 0.f : j3 > 0.f) ? d[v].w : 0.f;
-                    acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
-                    dw.x = fmaf(ci[v], t0, dw.x); dw.y = fmaf(ci[v], t1, dw.y); dw.z = fmaf(ci[v], t2, dw.z); dw.w = fmaf(ci[v], t3, dw.w);
-                }
+                if (ok[v]) edge_bwd_term<NEG>(ci[v], d[v], q[v], w, psend, acc, dw);
         }
     }
     acc = slot_reduce<SLOTS>(acc); dw = slot_reduce<SLOTS>(dw);

@@ -122,7 +122,7 @@ int gcnn_linear_bwd(float* dy, const float* ymask, const float* wa, const float*
  *           p_recv = projected table of the receiving side [n_recv,64] (constraint/cut side when from_v=True,
  *           model.py:553-556), p_oth = the other side's table, gathered by oth[e].
  *           Optional output for the backward pass: n_rows [n_recv,64] = number of active edges ([s1*J_e > 0]) per
- *           receiver and channel.  Nothing is stored per edge.
+ *           receiver and channel.  Nothing is stored per edge.  Tables hold at most 2^24 rows (gathers use 32-bit byte offsets).
  * bwd_recv: element-wise, because d_s[r] is constant over a segment: d_p_recv = s1*d_s*n_rows.
  * bwd_send: segments grouped by the SENDING node u; the ReLU pattern is recomputed from the two projected tables with the
  *           forward's own expression (bit-identical): with r = oth[e], J_e = (c_e*w_edge + p_send[u]) + p_recv[r] and
