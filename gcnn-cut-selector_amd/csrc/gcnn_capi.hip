@@ -145,9 +145,13 @@ static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool cou
     // inference on a small graph (one sampled state): latency, not lane efficiency, decides -- a whole wave per segment needs no
     // long-segment launch and finishes a hub row in a quarter of the gather rounds
     const int slots = (!count && a.n_own <= 16384) ? 4 : edge_slots(a.n_own, n_edges);
-    if (!count && a.n_own <= 1024 && n_edges >= 48ll * a.n_own) {   // a few long segments: a block each (k_edge_fwd_block)
-        ProfScope prof("k_edge_fwd_block", st);
-        hipLaunchKernelGGL(k_edge_fwd_block, dim3(a.n_own), dim3(256), 0, st, a);
+    // a few long segments: a block each (k_edge_fwd_block) -- the cut rows of one sampled state or of a stacked batch (1,893
+    // segments of ~105 edges at setcov x 32: a wave per segment walks seven dependent gather rounds on under two waves per SIMD,
+    // four waves per segment two).  The same rule with and without counts: training and inference forward add in the same order.
+    if (a.n_own <= 4096 && n_edges >= 48ll * a.n_own) {
+        ProfScope prof(count ? "k_edge_fwd_block<count>" : "k_edge_fwd_block", st);
+        if (count) hipLaunchKernelGGL(k_edge_fwd_block<true>, dim3(a.n_own), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_edge_fwd_block<false>, dim3(a.n_own), dim3(256), 0, st, a);
         LAUNCHCHK();
         return 0;
     }
@@ -162,8 +166,8 @@ static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool cou
     }
     if (edge_needs_long_pass(slots, max_deg)) {
         ProfScope prof(count ? "k_edge_fwd_long<count>" : "k_edge_fwd_long", st);
-        if (count) hipLaunchKernelGGL(k_edge_fwd_long<true>, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
-        else hipLaunchKernelGGL(k_edge_fwd_long<false>, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
+        if (count) hipLaunchKernelGGL(k_edge_fwd_long<true>, dim3(edge_long_grid(a.n_own)), dim3(64 * LONG_NW), 0, st, a, edge_long_threshold(slots));
+        else hipLaunchKernelGGL(k_edge_fwd_long<false>, dim3(edge_long_grid(a.n_own)), dim3(64 * LONG_NW), 0, st, a, edge_long_threshold(slots));
         LAUNCHCHK();
     }
     return 0;
@@ -186,7 +190,7 @@ static int launch_edge_bwd_send(EdgeArgs a, int n_edges, int max_deg, int* n_par
     if (edge_needs_long_pass(slots, max_deg)) {
         ProfScope prof("k_edge_bwd_send_long", st);
         a.dw_partial += (size_t)grid * EMB;
-        hipLaunchKernelGGL(k_edge_bwd_send_long, dim3(edge_long_grid(a.n_own)), dim3(256), 0, st, a, edge_long_threshold(slots));
+        hipLaunchKernelGGL(k_edge_bwd_send_long, dim3(edge_long_grid(a.n_own)), dim3(64 * LONG_NW), 0, st, a, edge_long_threshold(slots));
         LAUNCHCHK();
         *n_parts += edge_long_grid(a.n_own);
     }

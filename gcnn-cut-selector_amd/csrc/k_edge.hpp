@@ -177,60 +177,87 @@ __global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
     else edge_fwd_impl<SLOTS, COUNT, false>(a, s1, blockIdx.x, gridDim.x);
 }
 
-// Inference on ONE sampled state with long segments (the cut rows of conv v->k: a few dozen cuts of 10-200 nonzeros each): a
-// wave per segment would walk a dozen dependent gather rounds with most of the chip idle.  Here a 4-wave block serves one
-// segment, each wave a contiguous quarter, and the four partial sums are added in a fixed order.
+// One segment [beg, end) of receiver r by the NW waves of a block: each wave a contiguous share (a multiple of 16 edges), the NW
+// partial sums (and active-edge counts: COUNT, the training forward) added in a fixed order.  Block-uniform call.
+template <bool COUNT, int NW>
+__device__ __forceinline__ void edge_fwd_block_segment(const EdgeArgs& a, const float s1, const EdgeLane<4>& L, const float4 w, const float esh,
+                                                       const float esc, const int r, const int beg, const int end,
+                                                       float4 (*red)[16], float4 (*redn)[16]) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = ((end - beg + NW - 1) / NW + 15) & ~15;
+    const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
+    const EdgeSum t = s1 < 0.f ? edge_fwd_partial<4, COUNT, true>(a, L, w, esh, esc, r, b, e)
+                               : edge_fwd_partial<4, COUNT, false>(a, L, w, esh, esc, r, b, e);
+    if (lane < 16) { red[wv][lane] = t.acc; if (COUNT) redn[wv][lane] = t.cnt; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float4 p = red[0][lane];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+        *(float4*)(a.out + (size_t)r * EMB + L.ch) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
+    } else if (COUNT && threadIdx.x >= 64 && threadIdx.x < 80) {   // counts: integer-valued, any order gives the same bits
+        float4 p = redn[0][lane];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) { const float4 q = redn[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+        *(float4*)(a.cnt_rows + (size_t)r * EMB + L.ch) = p;
+    }
+    __syncthreads();
+}
+// A few long segments (the cut rows of conv v->k: a few dozen to a couple of thousand cuts of 10-200 nonzeros each): a wave per
+// segment would walk up to a dozen dependent gather rounds with most of the chip idle.  Here a 4-wave block serves one segment.
+template <bool COUNT>
 __device__ __forceinline__ void edge_fwd_block_body(const EdgeArgs& a, const int bid, const int nblk) {
-    __shared__ float4 red[4][16];
+    __shared__ float4 red[4][16], redn[COUNT ? 4 : 1][16];
     const float s1 = *a.s1;
     const EdgeLane<4> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int r = bid; r < a.n_own; r += nblk) {
-        const int beg = a.seg_ptr[r], end = a.seg_ptr[r + 1];
-        const int chunk = ((end - beg + 3) / 4 + 15) & ~15;
-        const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
-        const EdgeSum t = s1 < 0.f ? edge_fwd_partial<4, false, true>(a, L, w, esh, esc, r, b, e)
-                                   : edge_fwd_partial<4, false, false>(a, L, w, esh, esc, r, b, e);
-        if (lane < 16) red[wv][lane] = t.acc;
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            const float4 p0 = red[0][lane], p1 = red[1][lane], p2 = red[2][lane], p3 = red[3][lane];
-            *(float4*)(a.out + (size_t)r * EMB + L.ch) = make_float4(s1 * ((p0.x + p1.x) + (p2.x + p3.x)), s1 * ((p0.y + p1.y) + (p2.y + p3.y)),
-                                                                  s1 * ((p0.z + p1.z) + (p2.z + p3.z)), s1 * ((p0.w + p1.w) + (p2.w + p3.w)));
-        }
-        __syncthreads();
-    }
+    for (int r = bid; r < a.n_own; r += nblk)
+        edge_fwd_block_segment<COUNT, 4>(a, s1, L, w, esh, esc, r, a.seg_ptr[r], a.seg_ptr[r + 1], red, redn);
 }
-__global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) { edge_fwd_block_body(a, blockIdx.x, gridDim.x); }
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) { edge_fwd_block_body<COUNT>(a, blockIdx.x, gridDim.x); }
 
-// The rows the main kernel left out (longer than `thresh`), one wave each.  `body(r, beg, end)` is called wave-uniformly.
+// The rows the main kernel left out (longer than `thresh`): found and served by whole BLOCKS of LONG_NW waves.  Thread t of block b
+// looks at rows (q + t) * gridDim.x + b, q = 0, LONG_NW*64, ... -- neighbouring hub rows (capfac's 201 long rows open every
+// sample) land in different blocks -- the block lists its long rows in row order (ballots: a fixed order) and serves them one
+// after the other, all waves on one row (`body(r, beg, end)`, block-uniform): a 493-edge hub row of a combauc batch is four
+// gather rounds per wave instead of 31 for one wave alone (the launch went from 24 / 32 us to well under 10 there).
+#define LONG_NW 8
 template <class Body>
 __device__ __forceinline__ void edge_long_rows(const int* __restrict__ seg_ptr, int n_own, int thresh, Body body) {
-    const int lane = threadIdx.x & 63;
-    const int W = gridDim.x * 4, w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    for (int q0 = 0; (long long)q0 * W + w < n_own; q0 += 64) {   // wave w owns rows w, w + W, w + 2W, ...
-        const long long rr = (long long)(q0 + lane) * W + w;
+    constexpr int NT = 64 * LONG_NW;
+    __shared__ int lr[NT], lb[NT], le[NT], wcnt[LONG_NW];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long long NB = gridDim.x, b = blockIdx.x;
+    for (long long q0 = 0; q0 * NB + b < n_own; q0 += NT) {
+        const long long rr = (q0 + t) * NB + b;
         const int r = rr < n_own ? (int)rr : -1;
         int beg = 0, end = 0;
         if (r >= 0) { beg = seg_ptr[r]; end = seg_ptr[r + 1]; }
-        unsigned long long m = __ballot(end - beg > thresh);
-        while (m) {
-            const int b = __builtin_ctzll(m);
-            m &= m - 1;
-            body(__shfl(r, b), __shfl(beg, b), __shfl(end, b));
-        }
+        const bool is_long = end - beg > thresh;
+        const unsigned long long bal = __ballot(is_long);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int pos = __popcll(bal & ((1ull << lane) - 1)), total = 0;
+#pragma unroll
+        for (int k = 0; k < LONG_NW; ++k) { if (k < wv) pos += wcnt[k]; total += wcnt[k]; }
+        if (is_long) { lr[pos] = r; lb[pos] = beg; le[pos] = end; }
+        __syncthreads();
+        for (int i = 0; i < total; ++i) body(lr[i], lb[i], le[i]);
+        __syncthreads();   // the lists are rewritten by the next round
     }
 }
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_edge_fwd_long(EdgeArgs a, int thresh) {
+__global__ __launch_bounds__(64 * LONG_NW) void k_edge_fwd_long(EdgeArgs a, int thresh) {
+    __shared__ float4 red[LONG_NW][16], redn[COUNT ? LONG_NW : 1][16];
     const float s1 = *a.s1;
     const EdgeLane<4> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    if (s1 < 0.f) edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int r, int beg, int end) { edge_fwd_segment<4, COUNT, true>(a, s1, L, w, esh, esc, r, beg, end); });
-    else edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int r, int beg, int end) { edge_fwd_segment<4, COUNT, false>(a, s1, L, w, esh, esc, r, beg, end); });
+    edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int r, int beg, int end) {
+        edge_fwd_block_segment<COUNT, LONG_NW>(a, s1, L, w, esh, esc, r, beg, end, red, redn);
+    });
 }
 
 // Backward, receiver-ordered half, element-wise: dP_recv[r] = s1*dS[r]*N[r].  (The model fuses this into the epilogue of
@@ -259,8 +286,9 @@ __device__ __forceinline__ void edge_bwd_term(const float c, const float4 d, con
     acc.x += t0; acc.y += t1; acc.z += t2; acc.w += t3;
     dw.x = fmaf(c, t0, dw.x); dw.y = fmaf(c, t1, dw.y); dw.z = fmaf(c, t2, dw.z); dw.w = fmaf(c, t3, dw.w);
 }
+struct BwdSum { float4 acc, dw; };   // per lane group, after the slot reduction: sum_e t_e and sum_e c_e*t_e (both before the s1 factor)
 template <int SLOTS, bool NEG>
-__device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
+__device__ __forceinline__ BwdSum edge_bwd_send_partial(const EdgeArgs& a, const EdgeLane<SLOTS>& L, const float4 w,
                                                         const float esh, const float esc, const int u, const int beg, const int end) {
     constexpr int G = 16 * SLOTS, STEP = EDGE_UB * SLOTS;
     const int gl = L.gl, slot = L.slot, ch = L.ch;
@@ -305,25 +333,35 @@ __device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const
                 if (ok[v]) edge_bwd_term<NEG>(ci[v], d[v], q[v], w, psend, acc, dw);
         }
     }
-    acc = slot_reduce<SLOTS>(acc); dw = slot_reduce<SLOTS>(dw);
-    if (slot == 0) *(float4*)(a.out + (size_t)u * EMB + ch) = make_float4(s1 * acc.x, s1 * acc.y, s1 * acc.z, s1 * acc.w);
-    return dw;
+    BwdSum out;
+    out.acc = slot_reduce<SLOTS>(acc); out.dw = slot_reduce<SLOTS>(dw);
+    return out;
+}
+// ... of a whole segment by one lane group: stores dP_send[u], returns the segment's share of d w_edge
+template <int SLOTS, bool NEG>
+__device__ __forceinline__ float4 edge_bwd_send_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w,
+                                                        const float esh, const float esc, const int u, const int beg, const int end) {
+    const BwdSum t = edge_bwd_send_partial<SLOTS, NEG>(a, L, w, esh, esc, u, beg, end);
+    if (L.slot == 0) *(float4*)(a.out + (size_t)u * EMB + L.ch) = make_float4(s1 * t.acc.x, s1 * t.acc.y, s1 * t.acc.z, s1 * t.acc.w);
+    return t.dw;
 }
 // d w_edge = s1 * sum over ALL edges of c_e * t_e.  Every lane group adds up the shares of the segments it serves (a fixed
 // assignment, hence a fixed order), the groups of a wave and the four waves of a block are combined in a fixed order and the
 // block stores ONE 64-float partial -- instead of a [n_send,64] matrix written here and column-summed by another kernel.
-template <int SLOTS>
+template <int SLOTS, int NW = 4>
 __device__ __forceinline__ void edge_dw_block_store(float4 dw, const float s1, float* __restrict__ dst, const int ch) {
-    __shared__ float4 red[4][16];
+    __shared__ float4 red[NW][16];
     if (SLOTS <= 2) { dw.x += __shfl_xor(dw.x, 32); dw.y += __shfl_xor(dw.y, 32); dw.z += __shfl_xor(dw.z, 32); dw.w += __shfl_xor(dw.w, 32); }
     if (SLOTS == 1) { dw.x += __shfl_xor(dw.x, 16); dw.y += __shfl_xor(dw.y, 16); dw.z += __shfl_xor(dw.z, 16); dw.w += __shfl_xor(dw.w, 16); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane < 16) red[wv][lane] = dw;
     __syncthreads();
     if (threadIdx.x < 16) {
-        const float4 p0 = red[0][lane], p1 = red[1][lane], p2 = red[2][lane], p3 = red[3][lane];
-        *(float4*)(dst + ch) = make_float4(s1 * ((p0.x + p1.x) + (p2.x + p3.x)), s1 * ((p0.y + p1.y) + (p2.y + p3.y)),
-                                           s1 * ((p0.z + p1.z) + (p2.z + p3.z)), s1 * ((p0.w + p1.w) + (p2.w + p3.w)));
+        float4 p = make_float4((red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x), (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y),
+                               (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z), (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w));
+#pragma unroll
+        for (int k = 4; k < NW; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+        *(float4*)(dst + ch) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
     }
 }
 template <int SLOTS, bool NEG>
@@ -352,16 +390,30 @@ __global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
     const float s1 = *a.s1;
     if (s1 < 0.f) edge_bwd_send_impl<SLOTS, true>(a, s1); else edge_bwd_send_impl<SLOTS, false>(a, s1);
 }
-__global__ __launch_bounds__(256) void k_edge_bwd_send_long(EdgeArgs a, int thresh) {
+__global__ __launch_bounds__(64 * LONG_NW) void k_edge_bwd_send_long(EdgeArgs a, int thresh) {
+    __shared__ float4 red[LONG_NW][16];
     const float s1 = *a.s1;
     const EdgeLane<4> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto add = [&](const float4 dw) { dwsum.x += dw.x; dwsum.y += dw.y; dwsum.z += dw.z; dwsum.w += dw.w; };
-    if (s1 < 0.f) edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { add(edge_bwd_send_segment<4, true>(a, s1, L, w, esh, esc, u, beg, end)); });
-    else edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) { add(edge_bwd_send_segment<4, false>(a, s1, L, w, esh, esc, u, beg, end)); });
-    edge_dw_block_store<4>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);   // this wave's share of d w_edge over every long row of the block
+    edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) {
+        const int chunk = ((end - beg + LONG_NW - 1) / LONG_NW + 15) & ~15;
+        const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
+        const BwdSum t = s1 < 0.f ? edge_bwd_send_partial<4, true>(a, L, w, esh, esc, u, b, e) : edge_bwd_send_partial<4, false>(a, L, w, esh, esc, u, b, e);
+        dwsum.x += t.dw.x; dwsum.y += t.dw.y; dwsum.z += t.dw.z; dwsum.w += t.dw.w;
+        if (lane < 16) red[wv][lane] = t.acc;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float4 p = red[0][lane];
+#pragma unroll
+            for (int k = 1; k < LONG_NW; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+            *(float4*)(a.out + (size_t)u * EMB + L.ch) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
+        }
+        __syncthreads();
+    });
+    edge_dw_block_store<4, LONG_NW>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

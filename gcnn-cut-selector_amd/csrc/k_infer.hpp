@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_infer_s2(EdgeArgs e, IplanArgs ia, int 
     extern __shared__ int pre[];   // place blocks: [n_vars + 1]
     const int b = blockIdx.x;
     if (b >= edge_blocks) { iplan_place_body<256>(ia, pre, b - edge_blocks, gridDim.x - edge_blocks); return; }
-    if (BLOCKSEG) { edge_fwd_block_body(e, b, edge_blocks); return; }
+    if (BLOCKSEG) { edge_fwd_block_body<false>(e, b, edge_blocks); return; }
     const float s1 = *e.s1;
     if (s1 < 0.f) edge_fwd_impl<4, false, true>(e, s1, b, edge_blocks); else edge_fwd_impl<4, false, false>(e, s1, b, edge_blocks);
 }

@@ -9,7 +9,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 NOT_STEP = ("seg_sum", "seg_bcast", "iota", "gather_edges", "seg_offsets", "check_edges", "k_edge_fwd<4, false>",
-            "k_edge_fwd<2, false>", "k_edge_fwd<1, false>", "k_edge_fwd_block", "k_edge_fwd_long<false>", "k_iplan", "k_infer",
+            "k_edge_fwd<2, false>", "k_edge_fwd<1, false>", "k_edge_fwd_block<false>", "k_edge_fwd_long<false>", "k_iplan", "k_infer",
             "k_rank_scores", "k_collate", "k_stats", "k_expand")
 tot = 0.0
 print(f"{'kernel':72s} {'calls':>6s} {'avg_us':>9s} {'us/step':>9s}")

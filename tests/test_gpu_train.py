@@ -233,7 +233,10 @@ def test_dp_step_world1_equals_single_gpu_step(dev):
             m._backward_into(flat, batch, ws, d, ts.grads)
             opt.apply_flat(m, ts.grads)
         outs.append(m.flat_parameters.detach().cpu().numpy().copy())
-    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-7)
+    # the two branches scale the same gradient at different points (1/n inside the loss head vs a division in Adam): equal up to
+    # rounding, which Adam's first step g / (|g| + eps) magnifies for gradient entries around eps = 1e-7 -- hence the absolute
+    # term of one thousandth of a step (lr = 1e-3)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=1e-6)
 
 
 def test_train_step_on_degenerate_batches(dev):
