@@ -29,6 +29,13 @@
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Tuning knobs (tools/README.md): an experiment build (-DGCNN_TUNING, tools/mklib.sh) reads them from the environment once per
+// process; the product library is built without and every knob is its compile-time default -- no getenv on the launch path.
+#ifdef GCNN_TUNING
+#define GCNN_KNOB(name, dflt) ([] { static const int v_ = getenv(name) ? atoi(getenv(name)) : (dflt); return v_; }())
+#else
+#define GCNN_KNOB(name, dflt) (dflt)
+#endif
 // hipFuncSetAttribute acts on the current device's copy of a kernel: remember it per device, not per process
 #define GCNN_MAX_DEVICES 64
 struct PerDeviceOnce {
@@ -480,7 +487,7 @@ int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const fl
 static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0, int cap = 256) {
     int ntile[3], total = 0;
     for (int i = 0; i < ngroups; ++i) { ntile[i] = n[i] > 0 ? cdiv(n[i], 16) : 0; total += ntile[i]; }
-    static const int forced = getenv("GCNN_ROWS_WAVES") ? atoi(getenv("GCNN_ROWS_WAVES")) : 0;   // tuning knob (tools/README.md)
+    const int forced = GCNN_KNOB("GCNN_ROWS_WAVES", 0);
     const int nwaves = (forced == 4 || forced == 8) ? forced : (total > 1024 ? 8 : 4);
     int want[3], sum_want = 0;
     long long work[3], sum_work = 0;
@@ -512,7 +519,7 @@ static int rows_blocks(const int* n, const int* nstage, int ngroups, int* blk0, 
 // Few tiles (the cut rows of a training batch, every row set of a single-state inference call): one block of four waves per
 // tile, the waves sharing the tile's products (k_rows_split.hpp).  Blocks = tiles.
 static bool rows_split(const int* n, int ngroups, int* blk0) {
-    static const int max_tiles = getenv("GCNN_SPLIT_MAX_TILES") ? atoi(getenv("GCNN_SPLIT_MAX_TILES")) : 256;   // tuning knob (tools/README.md)
+    const int max_tiles = GCNN_KNOB("GCNN_SPLIT_MAX_TILES", 256);
     int total = 0;
     blk0[0] = 0;
     for (int i = 0; i < ngroups; ++i) { const int t = n[i] > 0 ? cdiv(n[i], 16) : 0; total += t; blk0[i + 1] = blk0[i] + t; }
@@ -553,7 +560,7 @@ static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
     }
     // the embedding programs stage three matrices (52 KB): two blocks fit a CU, and with many tiles per wave four waves per SIMD
     // overlap the store-heavy epilogues with the MFMAs better than two (capfac x 32, indset x 64)
-    static const int cap_knob = getenv("GCNN_EMB_CAP") ? atoi(getenv("GCNN_EMB_CAP")) : 0;   // tuning knob
+    const int cap_knob = GCNN_KNOB("GCNN_EMB_CAP", 0);
     const int tiles = cdiv(std::max(m.v.n, 0), 16) + cdiv(std::max(m.c.n, 0), 16) + cdiv(std::max(m.k.n, 0), 16);
     const int cap = cap_knob > 0 ? cap_knob : (tiles >= 8192 ? 512 : 256);
     const int nwaves = rows_blocks(n, ns, 3, m.blk0, cap);
@@ -859,7 +866,7 @@ static void place_wg(JobList& jl, float* partial) {
     int order[WG_MAX_JOBS], last = -1;
     for (int k = 0; k < jl.npend; ++k) {
         int pick = -1;
-        static const int share = getenv("GCNN_WG_SHARE") ? atoi(getenv("GCNN_WG_SHARE")) : 1;   // tuning knob
+        const int share = GCNN_KNOB("GCNN_WG_SHARE", 1);
         if (last >= 0 && share)
             for (int i = 0; i < jl.npend && pick < 0; ++i)
                 if (!used[i] && jl.pend[i].n == jl.pend[last].n && (jl.pend[i].x == jl.pend[last].x || jl.pend[i].d == jl.pend[last].d)) pick = i;
@@ -880,7 +887,7 @@ static void place_wg(JobList& jl, float* partial) {
         while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (blocks_at(mid * 16) > slots) lo = mid; else hi = mid; }
         rows = hi * 16;
     }
-    static const int forced = getenv("GCNN_WG_ROWS") ? atoi(getenv("GCNN_WG_ROWS")) : 0;   // tuning knob (tools/README.md)
+    const int forced = GCNN_KNOB("GCNN_WG_ROWS", 0);
     if (forced >= 16 && forced % 16 == 0 && blocks_at(forced) <= WG_MAX_SLABS) rows = forced;
     for (int k = 0; k < jl.npend; ++k) {
         const PendWg& q = jl.pend[order[k]];

@@ -43,10 +43,6 @@ template <int EXTRA>
 __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int col) {
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) {
-#ifdef WG_ABL_NOLOAD   // ablation build (tools/micro/run_wgrad_abl.sh): the launch without its global loads
-        t.x[s] = t.d[s] = t.k[s] = make_float4(1.f, 1.f, 1.f, 1.f); t.p0[s] = 0; t.p1[s] = 1;
-        continue;
-#endif
         const int r = min(row0 + 4 * s + g, rend - 1);   // callers guarantee rend > 0
         if (EXTRA == 2) {
             t.x[s] = make_float4(jb.x[(size_t)r * jb.f + min(col >> 2, jb.f - 1)], 0.f, 0.f, 0.f);   // lanes m >= f: scale 0 below
@@ -84,11 +80,7 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
             for (int va = 0; va < (EXTRA == 2 ? 1 : 4); ++va)
 #pragma unroll
                 for (int vb = 0; vb < 4; ++vb)
-#ifdef WG_ABL_NOMFMA   // ablation build: the launch without its MFMAs
-                    acc[va][vb][0] += xa[va] * db[vb];
-#else
                     acc[va][vb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[va], db[vb], acc[va][vb], 0, 0, 0);
-#endif
             cs.x += db[0]; cs.y += db[1]; cs.z += db[2]; cs.w += db[3];
             if (EXTRA == 1) {
                 const float deg = (float)(cur.p1[s] - cur.p0[s]);

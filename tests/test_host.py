@@ -315,3 +315,40 @@ def test_bench_gpus_n_launches_n_ranks_itself():
     assert shared.returncode != 0 and not shared.stdout.strip()
     wrong = run({"WORLD_SIZE": "1", "RANK": "0"})                           # ranks exist but not as many as --gpus says
     assert wrong.returncode != 0 and not wrong.stdout.strip()
+
+
+def test_out_of_memory_skips_a_batch_single_gpu_and_propagates_data_parallel(monkeypatch, capsys):
+    """The reference skips a batch that exhausts memory (model_trainer.py:308-311: `except ResourceExhaustedError: print(WARNING)`).
+    Single GPU: the same.  Data parallel: the peers are already in this step's all-reduce, so a rank must not skip on its own --
+    the error propagates (documented deviation).  Checked on the CPU with the device calls stubbed out."""
+    from gcnn_cut_selector_amd import trainer
+
+    class FakeModel:
+        device = torch.device("cpu")
+        flat_parameters = torch.zeros(8)
+
+        def prepare(self, inputs):
+            return inputs
+
+    calls = []
+
+    def oom_on_second(model, batch, y, optimizer, state, process_group=None):
+        calls.append(process_group)
+        if len(calls) == 2:
+            raise torch.OutOfMemoryError("HIP out of memory (simulated)")
+        return torch.ones(1), torch.zeros(3)
+
+    monkeypatch.setattr(trainer, "train_step", oom_on_second)
+    monkeypatch.setattr(trainer, "ranking_metric", lambda *a, **k: None)
+    z = np.zeros
+    batch = (z((1, 4), np.float32), z((2, 0), np.int32), z((0, 1), np.float32), z((1, 14), np.float32), z((3, 6), np.float32),
+             z((2, 0), np.int32), z((0, 1), np.float32), np.array([1]), np.array([1]), np.array([3]), z(3, np.float32))
+    opt = trainer.Adam(learning_rate=lambda: 1e-3)
+    fractions = np.array([0.25, 0.5, 0.75, 1])
+    loss, acc = trainer.process(FakeModel(), [batch, batch, batch], fractions, None, opt)      # the second batch is skipped
+    assert len(calls) == 3 and "WARNING: batch skipped." in capsys.readouterr().out
+    calls.clear()
+    monkeypatch.setattr(torch.distributed, "all_reduce", lambda *a, **k: None)
+    with pytest.raises(torch.OutOfMemoryError):
+        trainer.process(FakeModel(), [batch, batch, batch], fractions, None, opt, process_group="group")
+    assert calls == ["group", "group"]                                                            # stopped at the failing step

@@ -1,5 +1,5 @@
 #pragma once
-#include "k_edge.hpp"
+#include "../../gcnn-cut-selector_amd/csrc/k_edge.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Edge passes with the gathered table staged through LDS ("window" passes).

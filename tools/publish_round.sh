@@ -17,5 +17,5 @@ cp $S/dp_world1_strong.json profiles/${R}_dp_world1_strong.json
 cp $S/graph_replay.json profiles/${R}_graph_replay.json
 cp $S/single_sample_latency.txt profiles/${R}_single_sample_latency.txt
 cp $S/epoch_throughput.txt profiles/${R}_epoch_throughput.txt
-[ -f $S/bench_edge.txt ] && cp $S/bench_edge.txt profiles/${R}_bench_edge.txt
+
 echo published
