@@ -122,8 +122,9 @@ static inline int edge_slots(int n_own, int n_edges) {
 static inline bool edge_needs_long_pass(int slots, int max_deg) {
     return slots < 4 && (max_deg <= 0 || max_deg > edge_long_threshold(slots));
 }
-static inline int edge_long_grid(int n_own) { return std::max(1, std::min(cdiv(n_own, 4), MAX_GRID)); }
-static_assert(GCNN_EDGE_DW_PARTS >= EDGE_MAX_GRID + MAX_GRID, "dw partial rows: main launch + long-segment launch");
+// blocks that find and serve them, riding at the front of the pass's launch: a multiple of 8 (the other blocks' XCD remap)
+static inline int edge_long_grid(int n_own) { return (std::max(1, std::min(cdiv(n_own, 4), MAX_GRID)) + 7) & ~7; }
+static_assert(GCNN_EDGE_DW_PARTS >= EDGE_MAX_GRID + MAX_GRID + 8, "dw partial rows: main blocks + long-segment blocks");
 // forward (owner = receiver); `count` also emits the N rows (active edges per receiver and channel) for the backward pass
 static int launch_plan_place(const IplanArgs& ia, hipStream_t st);
 static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool count, hipStream_t st, const IplanArgs* plan = nullptr) {
@@ -163,18 +164,17 @@ static int launch_edge_fwd(const EdgeArgs& a, int n_edges, int max_deg, bool cou
         return 0;
     }
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), EDGE_MAX_GRID);
+    const int lb = edge_needs_long_pass(slots, max_deg) ? edge_long_grid(a.n_own) : 0;   // long-segment blocks, first in the grid
     {
-        ProfScope prof(count ? "k_edge_fwd<count>" : "k_edge_fwd", st);
-#define EDGE_LAUNCH(S, V) hipLaunchKernelGGL((k_edge_fwd<S, V>), dim3(grid), dim3(256), 0, st, a)
+        ProfScope prof(count ? (lb ? "k_edge_fwd<count> + long segments" : "k_edge_fwd<count>") : "k_edge_fwd", st);
+#define EDGE_LAUNCH(S, V)                                                                                              \
+        do {                                                                                                            \
+            if (lb) hipLaunchKernelGGL((k_edge_fwd<S, V, (S < 4)>), dim3(grid + lb), dim3(256), 0, st, a, lb);          \
+            else hipLaunchKernelGGL((k_edge_fwd<S, V, false>), dim3(grid), dim3(256), 0, st, a, 0);                     \
+        } while (0)
         if (count) { if (slots == 4) EDGE_LAUNCH(4, true); else if (slots == 2) EDGE_LAUNCH(2, true); else EDGE_LAUNCH(1, true); }
         else { if (slots == 4) EDGE_LAUNCH(4, false); else if (slots == 2) EDGE_LAUNCH(2, false); else EDGE_LAUNCH(1, false); }
 #undef EDGE_LAUNCH
-        LAUNCHCHK();
-    }
-    if (edge_needs_long_pass(slots, max_deg)) {
-        ProfScope prof(count ? "k_edge_fwd_long<count>" : "k_edge_fwd_long", st);
-        if (count) hipLaunchKernelGGL(k_edge_fwd_long<true>, dim3(edge_long_grid(a.n_own)), dim3(64 * LONG_NW), 0, st, a, edge_long_threshold(slots));
-        else hipLaunchKernelGGL(k_edge_fwd_long<false>, dim3(edge_long_grid(a.n_own)), dim3(64 * LONG_NW), 0, st, a, edge_long_threshold(slots));
         LAUNCHCHK();
     }
     return 0;
@@ -186,21 +186,15 @@ static int launch_edge_bwd_send(EdgeArgs a, int n_edges, int max_deg, int* n_par
     if (a.n_own <= 0) return 0;
     const int slots = edge_slots(a.n_own, n_edges);
     const int grid = std::min(cdiv(cdiv(a.n_own, 4 / slots), 4), EDGE_MAX_GRID);
-    *n_parts = grid;
-    {
-        ProfScope prof("k_edge_bwd_send", st);
-        if (slots == 4) hipLaunchKernelGGL(k_edge_bwd_send<4>, dim3(grid), dim3(256), 0, st, a);
-        else if (slots == 2) hipLaunchKernelGGL(k_edge_bwd_send<2>, dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(k_edge_bwd_send<1>, dim3(grid), dim3(256), 0, st, a);
-        LAUNCHCHK();
-    }
-    if (edge_needs_long_pass(slots, max_deg)) {
-        ProfScope prof("k_edge_bwd_send_long", st);
-        a.dw_partial += (size_t)grid * EMB;
-        hipLaunchKernelGGL(k_edge_bwd_send_long, dim3(edge_long_grid(a.n_own)), dim3(64 * LONG_NW), 0, st, a, edge_long_threshold(slots));
-        LAUNCHCHK();
-        *n_parts += edge_long_grid(a.n_own);
-    }
+    const int lb = edge_needs_long_pass(slots, max_deg) ? edge_long_grid(a.n_own) : 0;
+    *n_parts = grid + lb;
+    ProfScope prof(lb ? "k_edge_bwd_send + long segments" : "k_edge_bwd_send", st);
+    if (slots == 4) hipLaunchKernelGGL((k_edge_bwd_send<4, false>), dim3(grid), dim3(256), 0, st, a, 0);
+    else if (slots == 2 && lb) hipLaunchKernelGGL((k_edge_bwd_send<2, true>), dim3(grid + lb), dim3(256), 0, st, a, lb);
+    else if (slots == 2) hipLaunchKernelGGL((k_edge_bwd_send<2, false>), dim3(grid), dim3(256), 0, st, a, 0);
+    else if (lb) hipLaunchKernelGGL((k_edge_bwd_send<1, true>), dim3(grid + lb), dim3(256), 0, st, a, lb);
+    else hipLaunchKernelGGL((k_edge_bwd_send<1, false>), dim3(grid), dim3(256), 0, st, a, 0);
+    LAUNCHCHK();
     return 0;
 }
 

@@ -170,36 +170,45 @@ __device__ __forceinline__ void edge_fwd_impl(const EdgeArgs& a, const float s1,
     }
 }
 
-template <int SLOTS, bool COUNT>
-__global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a) {
+template <int SLOTS, bool COUNT> __device__ __forceinline__ void edge_fwd_long_body(const EdgeArgs& a, int nb, int b, int thresh);
+// LONG: the first `long_blocks` blocks (a multiple of 8, so that the XCD-aware remap of the others still holds) serve the segments
+// the others skip, see edge_long_rows: the same launch instead of a second one (4 launches fewer per capfac / combauc step).
+// A pass whose list has no long segment runs the LONG = false instantiation: the second body costs registers (a wave of occupancy
+// in the backward pass) and 2 % of a setcov step when it is merely present.
+template <int SLOTS, bool COUNT, bool LONG = false>
+__global__ __launch_bounds__(256) void k_edge_fwd(EdgeArgs a, int long_blocks) {
+    if (LONG && (int)blockIdx.x < long_blocks) { edge_fwd_long_body<SLOTS, COUNT>(a, long_blocks, blockIdx.x, edge_long_threshold(SLOTS)); return; }
     const float s1 = *a.s1;
-    if (s1 < 0.f) edge_fwd_impl<SLOTS, COUNT, true>(a, s1, blockIdx.x, gridDim.x);
-    else edge_fwd_impl<SLOTS, COUNT, false>(a, s1, blockIdx.x, gridDim.x);
+    const int bid = blockIdx.x - (LONG ? long_blocks : 0), nblk = gridDim.x - (LONG ? long_blocks : 0);
+    if (s1 < 0.f) edge_fwd_impl<SLOTS, COUNT, true>(a, s1, bid, nblk);
+    else edge_fwd_impl<SLOTS, COUNT, false>(a, s1, bid, nblk);
 }
 
-// One segment [beg, end) of receiver r by the NW waves of a block: each wave a contiguous share (a multiple of 16 edges), the NW
-// partial sums (and active-edge counts: COUNT, the training forward) added in a fixed order.  Block-uniform call.
-template <bool COUNT, int NW>
-__device__ __forceinline__ void edge_fwd_block_segment(const EdgeArgs& a, const float s1, const EdgeLane<4>& L, const float4 w, const float esh,
+// One segment [beg, end) of receiver r by ALL lane groups of a 256-thread block (4 waves x 64 / (16*SLOTS) groups): each group a
+// contiguous share, the partial sums (and active-edge counts: COUNT, the training forward) added in a fixed order.  Block-uniform
+// call.  (The groups run the very instantiation of edge_fwd_partial the one-group-per-segment blocks of the same kernel run.)
+template <int SLOTS, bool COUNT>
+__device__ __forceinline__ void edge_fwd_block_segment(const EdgeArgs& a, const float s1, const EdgeLane<SLOTS>& L, const float4 w, const float esh,
                                                        const float esc, const int r, const int beg, const int end,
                                                        float4 (*red)[16], float4 (*redn)[16]) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int chunk = ((end - beg + NW - 1) / NW + 15) & ~15;
-    const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
-    const EdgeSum t = s1 < 0.f ? edge_fwd_partial<4, COUNT, true>(a, L, w, esh, esc, r, b, e)
-                               : edge_fwd_partial<4, COUNT, false>(a, L, w, esh, esc, r, b, e);
-    if (lane < 16) { red[wv][lane] = t.acc; if (COUNT) redn[wv][lane] = t.cnt; }
+    constexpr int G = 16 * SLOTS, NG = 256 / G;
+    const int grp = threadIdx.x / G, lane = threadIdx.x & 63;
+    const int share = (end - beg + NG - 1) / NG;
+    const int b = min(end, beg + grp * share), e = min(end, b + share);
+    const EdgeSum t = s1 < 0.f ? edge_fwd_partial<SLOTS, COUNT, true>(a, L, w, esh, esc, r, b, e)
+                               : edge_fwd_partial<SLOTS, COUNT, false>(a, L, w, esh, esc, r, b, e);
+    if (L.gl < 16) { red[grp][L.gl] = t.acc; if (COUNT) redn[grp][L.gl] = t.cnt; }
     __syncthreads();
     if (threadIdx.x < 16) {
         float4 p = red[0][lane];
 #pragma unroll
-        for (int k = 1; k < NW; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
-        *(float4*)(a.out + (size_t)r * EMB + L.ch) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
+        for (int k = 1; k < NG; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+        *(float4*)(a.out + (size_t)r * EMB + 4 * lane) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
     } else if (COUNT && threadIdx.x >= 64 && threadIdx.x < 80) {   // counts: integer-valued, any order gives the same bits
         float4 p = redn[0][lane];
 #pragma unroll
-        for (int k = 1; k < NW; ++k) { const float4 q = redn[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
-        *(float4*)(a.cnt_rows + (size_t)r * EMB + L.ch) = p;
+        for (int k = 1; k < NG; ++k) { const float4 q = redn[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+        *(float4*)(a.cnt_rows + (size_t)r * EMB + 4 * lane) = p;
     }
     __syncthreads();
 }
@@ -213,23 +222,23 @@ __device__ __forceinline__ void edge_fwd_block_body(const EdgeArgs& a, const int
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
     for (int r = bid; r < a.n_own; r += nblk)
-        edge_fwd_block_segment<COUNT, 4>(a, s1, L, w, esh, esc, r, a.seg_ptr[r], a.seg_ptr[r + 1], red, redn);
+        edge_fwd_block_segment<4, COUNT>(a, s1, L, w, esh, esc, r, a.seg_ptr[r], a.seg_ptr[r + 1], red, redn);
 }
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) { edge_fwd_block_body<COUNT>(a, blockIdx.x, gridDim.x); }
 
-// The rows the main kernel left out (longer than `thresh`): found and served by whole BLOCKS of LONG_NW waves.  Thread t of block b
-// looks at rows (q + t) * gridDim.x + b, q = 0, LONG_NW*64, ... -- neighbouring hub rows (capfac's 201 long rows open every
+// The rows the main blocks leave out (longer than `thresh`): found and served by whole BLOCKS of LONG_NW waves.  Thread t of block b
+// (of nb) looks at rows (q + t) * nb + b, q = 0, LONG_NW*64, ... -- neighbouring hub rows (capfac's 201 long rows open every
 // sample) land in different blocks -- the block lists its long rows in row order (ballots: a fixed order) and serves them one
-// after the other, all waves on one row (`body(r, beg, end)`, block-uniform): a 493-edge hub row of a combauc batch is four
-// gather rounds per wave instead of 31 for one wave alone (the launch went from 24 / 32 us to well under 10 there).
-#define LONG_NW 8
+// after the other, all its lane groups on one row (`body(r, beg, end)`, block-uniform): a 493-edge hub row of a combauc batch is a
+// handful of gather rounds per group instead of 31 for one wave alone.
+#define LONG_NW 4
 template <class Body>
-__device__ __forceinline__ void edge_long_rows(const int* __restrict__ seg_ptr, int n_own, int thresh, Body body) {
+__device__ __forceinline__ void edge_long_rows(const int* __restrict__ seg_ptr, int n_own, int thresh, int nb, int blk, Body body) {
     constexpr int NT = 64 * LONG_NW;
     __shared__ int lr[NT], lb[NT], le[NT], wcnt[LONG_NW];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const long long NB = gridDim.x, b = blockIdx.x;
+    const long long NB = nb, b = blk;
     for (long long q0 = 0; q0 * NB + b < n_own; q0 += NT) {
         const long long rr = (q0 + t) * NB + b;
         const int r = rr < n_own ? (int)rr : -1;
@@ -248,15 +257,16 @@ __device__ __forceinline__ void edge_long_rows(const int* __restrict__ seg_ptr, 
         __syncthreads();   // the lists are rewritten by the next round
     }
 }
-template <bool COUNT>
-__global__ __launch_bounds__(64 * LONG_NW) void k_edge_fwd_long(EdgeArgs a, int thresh) {
-    __shared__ float4 red[LONG_NW][16], redn[COUNT ? LONG_NW : 1][16];
+template <int SLOTS, bool COUNT>
+__device__ __forceinline__ void edge_fwd_long_body(const EdgeArgs& a, int nb, int b, int thresh) {
+    constexpr int NG = 256 / (16 * SLOTS);
+    __shared__ float4 red[NG][16], redn[COUNT ? NG : 1][16];
     const float s1 = *a.s1;
-    const EdgeLane<4> L;
+    const EdgeLane<SLOTS> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int r, int beg, int end) {
-        edge_fwd_block_segment<COUNT, LONG_NW>(a, s1, L, w, esh, esc, r, beg, end, red, redn);
+    edge_long_rows(a.seg_ptr, a.n_own, thresh, nb, b, [&](int r, int beg, int end) {
+        edge_fwd_block_segment<SLOTS, COUNT>(a, s1, L, w, esh, esc, r, beg, end, red, redn);
     });
 }
 
@@ -365,7 +375,7 @@ __device__ __forceinline__ void edge_dw_block_store(float4 dw, const float s1, f
     }
 }
 template <int SLOTS, bool NEG>
-__device__ __forceinline__ void edge_bwd_send_impl(const EdgeArgs& a, const float s1) {
+__device__ __forceinline__ void edge_bwd_send_impl(const EdgeArgs& a, const float s1, const int bid, const int nblk) {
     constexpr int G = 16 * SLOTS, RPW = 64 / G;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const EdgeLane<SLOTS> L;
@@ -373,7 +383,7 @@ __device__ __forceinline__ void edge_bwd_send_impl(const EdgeArgs& a, const floa
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const int nwork = (a.n_own + RPW - 1) / RPW;
     float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wv; item < nwork; item += gridDim.x * 4) {
+    for (int item = xcd_remap(bid, nblk) * 4 + wv; item < nwork; item += nblk * 4) {
         const int u = item * RPW + lane / G;
         if (u < a.n_own) {
             const int beg = a.seg_ptr[u], end = a.seg_ptr[u + 1];
@@ -386,34 +396,39 @@ __device__ __forceinline__ void edge_bwd_send_impl(const EdgeArgs& a, const floa
     edge_dw_block_store<SLOTS>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
 }
 template <int SLOTS>
-__global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a) {
+__device__ __forceinline__ void edge_bwd_send_long_body(const EdgeArgs& a, int nb, int blk, int thresh) {
+    constexpr int G = 16 * SLOTS, NG = 256 / G;
+    __shared__ float4 red[NG][16];
     const float s1 = *a.s1;
-    if (s1 < 0.f) edge_bwd_send_impl<SLOTS, true>(a, s1); else edge_bwd_send_impl<SLOTS, false>(a, s1);
-}
-__global__ __launch_bounds__(64 * LONG_NW) void k_edge_bwd_send_long(EdgeArgs a, int thresh) {
-    __shared__ float4 red[LONG_NW][16];
-    const float s1 = *a.s1;
-    const EdgeLane<4> L;
+    const EdgeLane<SLOTS> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);   // this wave's share of d w_edge over every long row of the block
-    edge_long_rows(a.seg_ptr, a.n_own, thresh, [&](int u, int beg, int end) {
-        const int chunk = ((end - beg + LONG_NW - 1) / LONG_NW + 15) & ~15;
-        const int b = min(end, beg + wv * chunk), e = min(end, b + chunk);
-        const BwdSum t = s1 < 0.f ? edge_bwd_send_partial<4, true>(a, L, w, esh, esc, u, b, e) : edge_bwd_send_partial<4, false>(a, L, w, esh, esc, u, b, e);
+    const int grp = threadIdx.x / G, lane = threadIdx.x & 63;
+    float4 dwsum = make_float4(0.f, 0.f, 0.f, 0.f);   // this lane group's share of d w_edge over every long row of the block
+    edge_long_rows(a.seg_ptr, a.n_own, thresh, nb, blk, [&](int u, int beg, int end) {
+        const int share = (end - beg + NG - 1) / NG;
+        const int b = min(end, beg + grp * share), e = min(end, b + share);
+        const BwdSum t = s1 < 0.f ? edge_bwd_send_partial<SLOTS, true>(a, L, w, esh, esc, u, b, e) : edge_bwd_send_partial<SLOTS, false>(a, L, w, esh, esc, u, b, e);
         dwsum.x += t.dw.x; dwsum.y += t.dw.y; dwsum.z += t.dw.z; dwsum.w += t.dw.w;
-        if (lane < 16) red[wv][lane] = t.acc;
+        if (L.gl < 16) red[grp][L.gl] = t.acc;
         __syncthreads();
         if (threadIdx.x < 16) {
             float4 p = red[0][lane];
 #pragma unroll
-            for (int k = 1; k < LONG_NW; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
-            *(float4*)(a.out + (size_t)u * EMB + L.ch) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
+            for (int k = 1; k < NG; ++k) { const float4 q = red[k][lane]; p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w; }
+            *(float4*)(a.out + (size_t)u * EMB + 4 * lane) = make_float4(s1 * p.x, s1 * p.y, s1 * p.z, s1 * p.w);
         }
         __syncthreads();
     });
-    edge_dw_block_store<4, LONG_NW>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
+    edge_dw_block_store<SLOTS>(dwsum, s1, a.dw_partial + (size_t)blockIdx.x * EMB, L.ch);
+}
+// every block (long-row blocks first, see k_edge_fwd) leaves one partial row of d w_edge at dw_partial[blockIdx.x]
+template <int SLOTS, bool LONG = false>
+__global__ __launch_bounds__(256) void k_edge_bwd_send(EdgeArgs a, int long_blocks) {
+    if (LONG && (int)blockIdx.x < long_blocks) { edge_bwd_send_long_body<SLOTS>(a, long_blocks, blockIdx.x, edge_long_threshold(SLOTS)); return; }
+    const float s1 = *a.s1;
+    const int bid = blockIdx.x - (LONG ? long_blocks : 0), nblk = gridDim.x - (LONG ? long_blocks : 0);
+    if (s1 < 0.f) edge_bwd_send_impl<SLOTS, true>(a, s1, bid, nblk); else edge_bwd_send_impl<SLOTS, false>(a, s1, bid, nblk);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

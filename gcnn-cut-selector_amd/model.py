@@ -130,6 +130,18 @@ class _InferenceSession:
             # flags catch everything that is out of range but representable)
             if ei.dtype != np.int32 and ei.size and (int(ei.max()) > 2 ** 31 - 1 or int(ei.min()) < -2 ** 31):
                 raise ValueError("edge index out of range (left ids must be in [0,n_left), variable ids in [0,n_vars))")
+        # The specialised plan wants lists sorted by row, which is what get_state emits (utils.py:102-104).  A list in another order
+        # is sorted HERE while packing -- a stable argsort of a few 10^4 row ids costs tens of microseconds, the general path
+        # (device radix sorts + 20 launches) 0.4 ms.  Stable: entries of a row keep their input order, so every sum stays in a
+        # fixed order.
+        def by_row(ei, ef):
+            rows = ei[0]
+            if rows.size > 1 and bool((rows[1:] < rows[:-1]).any()):
+                order = np.argsort(rows, kind="stable")
+                return ei[:, order], ef.reshape(-1)[order]
+            return ei, ef
+        cei, cef = by_row(cei, cef)
+        kei, kef = by_row(kei, kef)
         key = (c.shape[0], v.shape[0], k.shape[0], cei.shape[1], kei.shape[1])
         lay = self._layout(key)
         if lay is False or (want_order and key[2] > 4096):

@@ -118,7 +118,10 @@ def test_full_batch_properties(dev, problem, batch):
     l1, s1 = train_step(m, prepared, yt, None, ts); g1 = ts.grads.clone()
     l2, _ = train_step(m, prepared, yt, None, ts)
     assert torch.equal(g1, ts.grads) and torch.equal(l1, l2)             # bitwise reproducible loss and gradients
-    np.testing.assert_allclose(s1.cpu().numpy(), a, rtol=1e-5, atol=1e-6)   # saving path vs inference path: same arithmetic
+    # saving path vs inference path: the same function; the inference forward gives small row sets a whole wave per segment while
+    # the training forward picks the lane group by mean degree (and splits hub rows over four waves), so segment sums are
+    # added in another (fixed) order
+    np.testing.assert_allclose(s1.cpu().numpy(), a, rtol=1e-4, atol=1e-5)
     assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
     # linearity of the backward pass in d_scores
     flat = m.flat_parameters.detach()

@@ -48,7 +48,8 @@ def test_concrete_function_matches_oracle_and_general_path(dev, problem):
 
 @pytest.mark.parametrize("problem", ["setcov", "combauc", "capfac", "indset"])
 def test_concrete_function_on_unsorted_coo(dev, problem):
-    """Edge lists in arbitrary order: the specialised plan declines (flag), the general path answers -- same scores."""
+    """Edge lists in arbitrary order: sorted by row on the host while packing (stable), then the specialised plan -- same scores as
+    the sorted state up to the order of the by-variable sums, and no detour through the general path."""
     m, params = _model(81, dev)
     f = m.get_concrete_function()
     state, _ = synthetic.make_sample(problem, 5)
@@ -56,7 +57,12 @@ def test_concrete_function_on_unsorted_coo(dev, problem):
     rng = np.random.default_rng(0)
     p1, p2 = rng.permutation(inp[1].shape[1]), rng.permutation(inp[5].shape[1])
     shuffled = (inp[0], inp[1][:, p1], inp[2][p1], inp[3], inp[4], inp[5][:, p2], inp[6][p2]) + inp[7:]
+    calls = []
+    general = m.call
+    m.call = lambda *a, **k: calls.append(1) or general(*a, **k)
     q = f(shuffled, False, rank=True)
+    m.call = general
+    assert not calls                                                     # answered by gcnn_infer, not by prepare + forward
     np.testing.assert_allclose(q.numpy(), _oracle(params, inp), rtol=1e-4, atol=1e-4)
     assert list(q.rankings) == sorted(range(len(q)), key=lambda x: q[x], reverse=True)
 
@@ -84,6 +90,16 @@ def test_score_state_edge_cases(dev):
     with torch.no_grad():
         assert np.array_equal(q.numpy(), m(inp, False).numpy())
     assert q[2] == q[5] and list(q.rankings) == sorted(range(K), key=lambda x: q[x], reverse=True)
+    # NaN scores (diverged weights): the device ranking must still be a permutation of 0..n-1 (NaNs rank last, in index order)
+    from gcnn_cut_selector_amd.model import GCNN
+    mn = GCNN(device=dev, seed=5)
+    w = mn.get_weights(); w[-1][:] = np.nan; mn.set_weights(w)           # out_2/bias = NaN -> every score NaN
+    qn = mn.score_state(inp, rank="device")
+    assert np.isnan(qn.numpy()).all() and sorted(qn.rankings.tolist()) == list(range(K)) and list(qn.rankings) == list(range(K))
+    # an int64 index beyond int32 must not wrap into range while it is packed
+    big = list(inp); big[1] = inp[1].astype(np.int64); big[1][1, 3] += 2 ** 32
+    with pytest.raises(ValueError):
+        m.score_state(tuple(big))
     # no cuts, no edges
     st = (rng.standard_normal((4, 4)).astype(f32), np.array([[0, 1], [1, 0]], i32), rng.standard_normal((2, 1)).astype(f32),
           rng.standard_normal((3, 14)).astype(f32), np.zeros((0, 6), f32), z2, np.zeros((0, 1), f32), 4, 3, 0)

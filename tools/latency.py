@@ -10,6 +10,7 @@ f = m.get_concrete_function()
 med = lambda xs: float(np.median(xs)) * 1e3
 for prob in ["setcov", "combauc", "capfac", "indset"]:
     state, _ = synthetic.make_sample(prob, 7)
+    rng = np.random.default_rng(0)
     inp = utils.state_to_inputs(state)
     for _ in range(10): f(inp, False).numpy()
     t_fast, t_rank, t_gen = [], [], []
@@ -30,3 +31,11 @@ for prob in ["setcov", "combauc", "capfac", "indset"]:
           f"general path (prepare + forward) {med(t_gen):.3f} ms   kernels: {len(prof.launches)} launches, {dev_us:.0f} us under event brackets")
     print(f"          host phases: pack {med(tm['pack']) * 1e3:.0f} us, enqueue (copies + {len(prof.launches)} launches) {med(tm['enqueue']) * 1e3:.0f} us, wait for the stream {med(tm['wait']) * 1e3:.0f} us")
     print("          " + "  ".join(f"{n}:{ms * 1e3:.1f}" for n, ms in prof.launches))
+    # the same state with its edge lists in random order: sorted by row on the host while packing, then the same single call
+    p1, p2 = rng.permutation(inp[1].shape[1]), rng.permutation(inp[5].shape[1])
+    shuf = (inp[0], inp[1][:, p1], inp[2][p1], inp[3], inp[4], inp[5][:, p2], inp[6][p2]) + inp[7:]
+    for _ in range(5): f(shuf, False).numpy()
+    t_un = []
+    for _ in range(30):
+        t0 = time.perf_counter(); f(shuf, False).numpy(); t_un.append(time.perf_counter() - t0)
+    print(f"          unsorted edge lists (host sort while packing + gcnn_infer): {med(t_un):.3f} ms")

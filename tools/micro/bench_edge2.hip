@@ -7,6 +7,9 @@
 #define KHDR "../../gcnn-cut-selector_amd/csrc/k_edge.hpp"
 #endif
 #include KHDR
+#ifndef LAUNCH_EXTRA   // trailing kernel arguments: the library's kernels take the number of long-segment blocks (-DLAUNCH_EXTRA= for a header without)
+#define LAUNCH_EXTRA , 0
+#endif
 #include <cstdio>
 #include <random>
 #include <vector>
@@ -73,11 +76,11 @@ int main(int argc, char** argv) {
 #define AB(SL)                                                                                                                       \
         {                                                                                                                            \
             const int grid = std::min(cdiv(cdiv(a.n_own, 4 / SL), 4), 8192);                                                         \
-            snprintf(nm, 96, "fwd<count> dir=%d slots=%d", dir, SL); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_fwd<SL, true>), dim3(grid), dim3(256), 0, 0, a); }); \
+            snprintf(nm, 96, "fwd<count> dir=%d slots=%d", dir, SL); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_fwd<SL, true>), dim3(grid), dim3(256), 0, 0, a LAUNCH_EXTRA); }); \
             csum("S", S, a.n_own); csum("N", N, a.n_own);                                                                            \
-            snprintf(nm, 96, "fwd dir=%d slots=%d", dir, SL); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_fwd<SL, false>), dim3(grid), dim3(256), 0, 0, a); }); \
+            snprintf(nm, 96, "fwd dir=%d slots=%d", dir, SL); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_fwd<SL, false>), dim3(grid), dim3(256), 0, 0, a LAUNCH_EXTRA); }); \
             csum("S (no count)", S, a.n_own);                                                                                        \
-            snprintf(nm, 96, "bwd_send dir=%d slots=%d", dir, SL); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_bwd_send<SL>), dim3(grid), dim3(256), 0, 0, a); }); \
+            snprintf(nm, 96, "bwd_send dir=%d slots=%d", dir, SL); timeit(nm, [&] { hipLaunchKernelGGL((k_edge_bwd_send<SL>), dim3(grid), dim3(256), 0, 0, a LAUNCH_EXTRA); }); \
             csum("dP_send", S, a.n_own); csum("dw partials", Q, grid);                                                               \
         }
         AB(4) AB(2) AB(1)
