@@ -504,6 +504,7 @@ def main():
                    "launch": launch, "library_launches_per_step": n_launches, "problem": args.problem, "batch_per_gpu" if args.scaling == "weak" else "global_batch_samples": args.batch,
                    "global_batch": args.batch * world if args.scaling == "weak" else args.batch, "edges_per_step": edges_total,
                    "n_cons": batch.dims.n_cons, "n_vars": batch.dims.n_vars, "n_cuts": batch.dims.n_cuts,
+                   "n_cons_edges": batch.dims.n_cons_edges, "n_cut_edges": batch.dims.n_cut_edges,
                    "parallelism": f"dp{world}", "final_loss": float(loss)},
         "distributed": {"world_size_env": world, "world_size_observed": world_seen,
                         "collective": ("rccl all_reduce (torch.distributed backend nccl), one flat fp32 buffer of "

@@ -257,7 +257,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 9; }
+int gcnn_abi_version(void) { return 10; }
 
 int gcnn_profile_begin(void) {
     int d = 0;
@@ -819,6 +819,24 @@ extern "C" int gcnn_infer(const gcnn_dims* d, const float* params, const void* h
     }
     HIPCHK(hipMemcpyAsync((char*)out + L.out_off[2], ia.flags, 16, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(host_out, out, L.out_bytes, hipMemcpyDeviceToHost, st));  // ONE download: scores | order | flags
+    return 0;
+}
+
+// host side of the single-state call: stable counting sort of an unsorted edge list by row, straight into the staging buffer
+extern "C" int gcnn_host_sort_edges_by_row(const int32_t* rows, const int32_t* cols, const float* vals, int32_t n_edges, int32_t n_left,
+                                           int32_t* out_inds, float* out_vals, int32_t* scratch) {
+    if (n_edges < 0 || n_left < 0 || (n_edges > 0 && (!rows || !cols || !vals || !out_inds || !out_vals || !scratch))) return GCNN_E_BADARG;
+    for (int i = 0; i <= n_left; ++i) scratch[i] = 0;
+    for (int e = 0; e < n_edges; ++e) {
+        const int r = rows[e];
+        if (r < 0 || r >= n_left) return GCNN_E_BADARG;
+        ++scratch[r + 1];
+    }
+    for (int i = 0; i < n_left; ++i) scratch[i + 1] += scratch[i];      // scratch[r] = first output slot of row r
+    for (int e = 0; e < n_edges; ++e) {
+        const int at = scratch[rows[e]]++;
+        out_inds[at] = rows[e]; out_inds[n_edges + at] = cols[e]; out_vals[at] = vals[e];
+    }
     return 0;
 }
 

@@ -90,6 +90,7 @@ class _InferenceSession:
         self.model = model
         self.pin_in = self.pin_out = self.arena = None
         self.in_np = self.out_np = None
+        self.sort_scratch = None
         self.layouts = {}
 
     def _layout(self, key):
@@ -131,17 +132,9 @@ class _InferenceSession:
             if ei.dtype != np.int32 and ei.size and (int(ei.max()) > 2 ** 31 - 1 or int(ei.min()) < -2 ** 31):
                 raise ValueError("edge index out of range (left ids must be in [0,n_left), variable ids in [0,n_vars))")
         # The specialised plan wants lists sorted by row, which is what get_state emits (utils.py:102-104).  A list in another order
-        # is sorted HERE while packing -- a stable argsort of a few 10^4 row ids costs tens of microseconds, the general path
-        # (device radix sorts + 20 launches) 0.4 ms.  Stable: entries of a row keep their input order, so every sum stays in a
-        # fixed order.
-        def by_row(ei, ef):
-            rows = ei[0]
-            if rows.size > 1 and bool((rows[1:] < rows[:-1]).any()):
-                order = np.argsort(rows, kind="stable")
-                return ei[:, order], ef.reshape(-1)[order]
-            return ei, ef
-        cei, cef = by_row(cei, cef)
-        kei, kef = by_row(kei, kef)
+        # is sorted while it is packed: a stable counting sort on the host (gcnn_host_sort_edges_by_row: tens of microseconds for
+        # a few 10^4 entries; NumPy's stable argsort alone would take longer than the whole general path).
+        unsorted = [ei.shape[1] > 1 and bool((ei[0, 1:] < ei[0, :-1]).any()) for ei in (cei, kei)]
         key = (c.shape[0], v.shape[0], k.shape[0], cei.shape[1], kei.shape[1])
         lay = self._layout(key)
         if lay is False or (want_order and key[2] > 4096):
@@ -159,11 +152,26 @@ class _InferenceSession:
             self.arena = torch.empty(max(2 * L.arena_bytes, 1 << 24), dtype=torch.uint8, device=dev)
         buf = self.in_np
         buf[in_off[0]:in_off[1]] = 0      # the plan's counters and flags travel zeroed inside the upload
-        for off, a, dt in ((in_off[1], c, np.float32), (in_off[2], cei, np.int32), (in_off[3], cef, np.float32),
-                           (in_off[4], v, np.float32), (in_off[5], k, np.float32), (in_off[6], kei, np.int32),
-                           (in_off[7], kef, np.float32)):
+        base = self.pin_in.data_ptr()
+        for off, a, dt in ((in_off[1], c, np.float32), (in_off[4], v, np.float32), (in_off[5], k, np.float32)):
             if a.size:
                 np.copyto(buf[off:off + 4 * a.size].view(dt).reshape(a.shape), a, casting="unsafe")
+        for (io, fo, ei, ef, n_left), uns in zip(((in_off[2], in_off[3], cei, cef, key[0]), (in_off[6], in_off[7], kei, kef, key[2])), unsorted):
+            if not ei.size:
+                continue
+            done = False
+            if uns:   # rows / cols / values as contiguous int32 / fp32, then one native pass into the staging buffer
+                ei32 = np.ascontiguousarray(ei, dtype=np.int32)
+                ef32 = np.ascontiguousarray(ef, dtype=np.float32).reshape(-1)
+                if self.sort_scratch is None or self.sort_scratch.size < n_left + 1:
+                    self.sort_scratch = np.empty(2 * (n_left + 1), np.int32)
+                rc = _lib.lib().gcnn_host_sort_edges_by_row(
+                    C.c_void_p(ei32.ctypes.data), C.c_void_p(ei32.ctypes.data + 4 * ei32.shape[1]), C.c_void_p(ef32.ctypes.data),
+                    ei32.shape[1], n_left, C.c_void_p(base + io), C.c_void_p(base + fo), C.c_void_p(self.sort_scratch.ctypes.data))
+                done = rc == 0            # a row id out of range: packed as it is, the device check raises
+            if not done:
+                np.copyto(buf[io:io + 4 * ei.size].view(np.int32).reshape(ei.shape), ei, casting="unsafe")
+                np.copyto(buf[fo:fo + 4 * ef.size].view(np.float32).reshape(ef.shape), ef, casting="unsafe")
         t1 = time.perf_counter()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)

@@ -183,6 +183,14 @@ int gcnn_infer_layout_for(const gcnn_dims* dims, gcnn_infer_layout* layout /* ho
 int gcnn_infer(const gcnn_dims* dims, const float* params, const void* host_in, void* host_out, void* arena,
                size_t arena_bytes, int32_t want_order, void* stream);
 
+/* Host helper of gcnn_infer (no device work): an edge list that is NOT sorted by row -- get_state emits sorted lists
+ * (utils.py:102-104), other producers may not -- is brought into row order while it is packed into the staging buffer: a stable
+ * counting sort (entries of a row keep their input order), O(E + n_left), a few tens of microseconds for a few 10^4 entries.
+ * rows / cols / vals: the list (host); out_inds [2,E] and out_vals [E] (host, e.g. inside host_in); scratch: n_left + 1 ints (host).
+ * Returns 0, or GCNN_E_BADARG when a row id lies outside [0, n_left) (nothing is written then: the device check reports it). */
+int gcnn_host_sort_edges_by_row(const int32_t* rows, const int32_t* cols, const float* vals, int32_t n_edges, int32_t n_left,
+                                int32_t* out_inds, float* out_vals, int32_t* scratch);
+
 /* Keras-form Adam step (see gcnn_adam_step) to run right behind a backward pass. */
 typedef struct gcnn_adam_args {
     float* params; float* m; float* v;   /* flat buffers, gcnn_param_total_floats() each; params is updated in place */
