@@ -219,6 +219,8 @@ struct Work {
     float* dwp[3];        // per-block partials of d w_edge, one [GCNN_EDGE_DW_PARTS,64] array per convolution
     float* dwp2[3];       // ... and their pre-reduction to [GCNN_EDGE_DW_PARTS / DW_CHUNK, 64] (k_wgrad's third block type)
     float* nrow[3];          // per receiver and channel: number of active edges
+    float* fuse[3];          // folded weights of each convolution: M [64,64] | u [64]  (fuse_weights)
+    float* gfuse[3];         // their raw gradients out of the weight-gradient launch: G1 [64,64] | g2 [64]  (k_fold_grads)
     float* score_partial; int score_nblk;
     double* stats; int* stat_ids;   // pretraining: per-block partial sums; explicit left ids of an edge set
     size_t total;
@@ -247,6 +249,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     for (int i = 0; i < 3; ++i) {
         w->dwp[i] = take((size_t)GCNN_EDGE_DW_PARTS * EMB); w->dwp2[i] = take((size_t)(GCNN_EDGE_DW_PARTS / DW_CHUNK) * EMB);
         w->nrow[i] = take(nrecv[i] * EMB);
+        w->fuse[i] = take(FUSE_FLOATS); w->gfuse[i] = take(FUSE_FLOATS);
     }
     w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
     w->stat_ids = (int*)take((size_t)std::max(d->n_cons_edges, d->n_cut_edges));
@@ -548,8 +551,8 @@ static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
         if (plan) {
             plan->blocks0 = std::min(cdiv(plan->s[0].n_edges + 1, 256), 32);
             plan->blocks1 = std::min(cdiv(plan->s[1].n_edges + 1, 256), 8);
-            SPLIT_LAUNCH("k_infer_s1 (embeddings + plan: count)", (k_infer_s1<4, true>), m.blk0[3] + plan->blocks0 + plan->blocks1, smem, st, m, *plan);
-        } else if (m.blk0[3] > 0) SPLIT_LAUNCH("k_embed_fwd_split", k_embed_fwd_split, m.blk0[3], smem, st, m);
+            SPLIT_LAUNCH("k_infer_s1 (embeddings + plan: count)", (k_infer_s1<4, true>), m.blk0[3] + 3 + plan->blocks0 + plan->blocks1, smem, st, m, *plan);
+        } else if (m.blk0[3] > 0) SPLIT_LAUNCH("k_embed_fwd_split", k_embed_fwd_split, m.blk0[3] + 3, smem, st, m);   // + fuse_weights
         return 0;
     }
     // the embedding programs stage three matrices (52 KB): two blocks fit a CU, and with many tiles per wave four waves per SIMD
@@ -562,15 +565,18 @@ static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
         const int nt = nwaves * 64;
         plan->blocks0 = std::min(cdiv(plan->s[0].n_edges + 1, nt), 32);   // few blocks, looping: they hold a CU slot of this launch's size
         plan->blocks1 = std::min(cdiv(plan->s[1].n_edges + 1, nt), 8);
-        const int grid = m.blk0[3] + plan->blocks0 + plan->blocks1;
+        const int grid = m.blk0[3] + 3 + plan->blocks0 + plan->blocks1;
         ROWS_LAUNCH("k_infer_s1 (embeddings + plan: count)", k_infer_s1<8>, k_infer_s1<4>, nwaves, grid, EMB_LDS_FLOATS * sizeof(float), st, m, *plan);
         return 0;
     }
     if (m.blk0[3] == 0) return 0;
-    ROWS_LAUNCH("k_embed_fwd", k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3], EMB_LDS_FLOATS * sizeof(float), st, m);
+    // + 3 blocks: fuse_weights, the folded matrices of the three convolutions (two blocks of this launch fit a CU, so they do not
+    // queue behind the embedding blocks)
+    ROWS_LAUNCH("k_embed_fwd", k_embed_fwd<8>, k_embed_fwd<4>, nwaves, m.blk0[3] + 3, EMB_LDS_FLOATS * sizeof(float), st, m);
     return 0;
 }
-static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, hipStream_t st) {
+// keep_a: the two-layer form that materialises A (PreNorm fitting); never together with a plan
+static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, hipStream_t st, bool keep_a = false) {
     int blk0[2];
     const int ns = 4;
     if (rows_split(&a.n, 1, blk0)) {
@@ -586,7 +592,10 @@ static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, 
             LAUNCHCHK();
         }
         if (blk0[1] == 0) return 0;
-        if (tail == CF_READOUT) SPLIT_LAUNCH("k_conv_fwd<readout>", k_conv_fwd_split<CF_READOUT>, blk0[1], smem, st, a);
+        if (keep_a) {
+            if (tail == CF_READOUT) SPLIT_LAUNCH("k_conv_fwd<readout, keep A>", (k_conv_fwd_split<CF_READOUT, true>), blk0[1], smem, st, a);
+            else SPLIT_LAUNCH("k_conv_fwd<proj, keep A>", (k_conv_fwd_split<CF_PROJ, true>), blk0[1], smem, st, a);
+        } else if (tail == CF_READOUT) SPLIT_LAUNCH("k_conv_fwd<readout>", k_conv_fwd_split<CF_READOUT>, blk0[1], smem, st, a);
         else SPLIT_LAUNCH("k_conv_fwd<proj>", k_conv_fwd_split<CF_PROJ>, blk0[1], smem, st, a);
         return 0;
     }
@@ -604,7 +613,10 @@ static int launch_conv_fwd(const ConvFArgs& a, int tail, const IplanArgs* plan, 
         LAUNCHCHK();
     }
     if (blk0[1] == 0) return 0;
-    if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout>", (k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
+    if (keep_a) {
+        if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout, keep A>", (k_conv_fwd<8, CF_READOUT, true>), (k_conv_fwd<4, CF_READOUT, true>), nwaves, blk0[1], smem, st, a);
+        else ROWS_LAUNCH("k_conv_fwd<proj, keep A>", (k_conv_fwd<8, CF_PROJ, true>), (k_conv_fwd<4, CF_PROJ, true>), nwaves, blk0[1], smem, st, a);
+    } else if (tail == CF_READOUT) ROWS_LAUNCH("k_conv_fwd<readout>", (k_conv_fwd<8, CF_READOUT>), (k_conv_fwd<4, CF_READOUT>), nwaves, blk0[1], smem, st, a);
     else ROWS_LAUNCH("k_conv_fwd<proj>", (k_conv_fwd<8, CF_PROJ>), (k_conv_fwd<4, CF_PROJ>), nwaves, blk0[1], smem, st, a);
     return 0;
 }
@@ -647,6 +659,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     float *PL, *PR, *S, *A, *Z1, *OUT;
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *DWP, *DWP2;
     float* N;
+    float *FZ, *GFZ;       // folded weights M | u and their raw gradients G1 | g2
 };
 
 static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
@@ -664,14 +677,15 @@ static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
 struct LossHead { const float* targets; float scale; float* g_o1; float* partial; };   // CF_LOSS extras
 static ConvBArgs conv_bwd_args(const float* p, const ConvIO& c, const float* in, const float* w0);
 static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t st, const float* wt, const float* bt,
-                        float* t_out, int tail, float* scores, const LossHead* head, const IplanArgs* plan = nullptr) {
+                        float* t_out, int tail, float* scores, const LossHead* head, const IplanArgs* plan = nullptr, bool keep_a = false) {
     int rc;
     EdgeArgs e = conv_edge_args(p, c, c.recv_left);
     e.out = c.S; e.cnt_rows = c.N;
     if ((rc = launch_edge_fwd(e, c.ne, c.recv_left ? c.g->l_max_deg : c.g->v_max_deg, save, st, plan))) return rc;
     ConvFArgs a; memset(&a, 0, sizeof(a));
     a.n = c.recv_left ? c.nl : c.nv;
-    a.s = c.S; a.seg_ptr = e.seg_ptr; a.wf = p + poff(c.pbase + C_WF); a.bf = p + poff(c.pbase + C_BF); a.a_out = save ? c.A : nullptr;
+    a.s = c.S; a.seg_ptr = e.seg_ptr; a.wf = p + poff(c.pbase + C_WF); a.bf = p + poff(c.pbase + C_BF); a.a_out = keep_a ? c.A : nullptr;
+    a.mfuse = c.FZ; a.ufuse = c.FZ + EMB * EMB;
     a.s2 = p + poff(c.pbase + C_S2); a.xrecv = c.recv_left ? c.xl : c.xv;
     a.w1a = p + poff(c.pbase + C_W1); a.w1b = p + poff(c.pbase + C_W1) + EMB * EMB; a.b1 = p + poff(c.pbase + C_B1);
     a.z1 = save ? c.Z1 : nullptr;
@@ -682,17 +696,17 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
         a.targets = head->targets; a.loss_scale = head->scale; a.g_o1 = head->g_o1; a.head_partial = head->partial;
         return launch_conv_turn(a, conv_bwd_args(p, c, head->g_o1, wt), st);
     }
-    return launch_conv_fwd(a, tail, plan, st);
+    return launch_conv_fwd(a, tail, plan, st, keep_a);
 }
 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0]};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0], w.fuse[0], w.gfuse[0]};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1]};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1], w.fuse[1], w.gfuse[1]};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2]};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2], w.fuse[2], w.gfuse[2]};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -709,8 +723,9 @@ static int check_common(const gcnn_dims* d, const float* params, const gcnn_grap
 // `targets` != nullptr: the last launch also evaluates the MSE head and the readout's Dense(64->1) gradient (CF_LOSS)
 static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                         const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
-                        size_t workspace_floats, float* scores, bool save, const float* targets, float loss_scale,
+                        size_t workspace_floats, float* scores, int save_mode, const float* targets, float loss_scale,
                         hipStream_t st, IplanArgs* plan = nullptr) {
+    const bool save = save_mode != 0, keep_a = save_mode == 2;   // 2: also materialise A of every convolution (PreNorm fitting)
     layout_init();
     int rc = check_common(d, p, cg, kg, workspace, workspace_floats);
     if (rc) return rc;
@@ -732,26 +747,32 @@ static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_fe
         m.c.wp[0] = p + poff(P_CONV0 + C_WL); m.c.bp[0] = p + poff(P_CONV0 + C_BL); m.c.po[0] = A.PL1;
         emb(m.k, cut_feats, P_CUT, A.E1k, A.Xk, d->n_cuts);    // cuts: E1 -> Xk -> PL3
         m.k.wp[0] = p + poff(P_CONV2 + C_WL); m.k.bp[0] = p + poff(P_CONV2 + C_BL); m.k.po[0] = A.PL3;
+        const int convs[3] = {P_CONV0, P_CONV1, P_CONV2};     // the folded weights of the three convolutions ride in this launch
+        for (int k = 0; k < 3; ++k) {
+            m.fz.wf[k] = p + poff(convs[k] + C_WF); m.fz.bf[k] = p + poff(convs[k] + C_BF); m.fz.s2[k] = p + poff(convs[k] + C_S2);
+            m.fz.w1a[k] = p + poff(convs[k] + C_W1); m.fz.out[k] = w.fuse[k];
+        }
         if ((rc = launch_embed_fwd(m, plan, st))) return rc;
     }
     // convolutions (model.py:294-296), each followed in the same launch by what consumes its output
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
     // updated constraints -> left projection of conv c->v
-    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, CF_PROJ, nullptr, nullptr, plan))) return rc;
+    if ((rc = conv_forward(p, cv[0], save, st, p + poff(P_CONV1 + C_WL), p + poff(P_CONV1 + C_BL), A.PL2, CF_PROJ, nullptr, nullptr, plan, keep_a))) return rc;
     // updated variables -> right projection of conv v->k
-    if ((rc = conv_forward(p, cv[1], save, st, p + poff(P_CONV2 + C_WR), nullptr, A.PR3, CF_PROJ, nullptr, nullptr))) return rc;
+    if ((rc = conv_forward(p, cv[1], save, st, p + poff(P_CONV2 + C_WR), nullptr, A.PR3, CF_PROJ, nullptr, nullptr, nullptr, keep_a))) return rc;
     // updated cuts -> readout (model.py:206-208, 299-300)
     if (targets) {   // O1 itself is not needed afterwards: its ReLU mask is folded into dO1pre, its values into the dws partials
         const LossHead head = {targets, loss_scale, w.g.O1, w.score_partial};
         return conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), nullptr, CF_LOSS, scores, &head);
     }
-    return conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), save ? A.O1 : nullptr, CF_READOUT, scores, nullptr);
+    return conv_forward(p, cv[2], save, st, p + poff(P_OUT), p + poff(P_OUT + 1), save ? A.O1 : nullptr, CF_READOUT, scores, nullptr, nullptr, keep_a);
 }
 extern "C" int gcnn_forward(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,
                  const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                  size_t workspace_floats, float* scores, int32_t save_for_backward, void* stream) {
+    if (save_for_backward < 0 || save_for_backward > 2) return GCNN_E_BADARG;
     return forward_impl(d, p, cons_feats, var_feats, cut_feats, cg, kg, workspace, workspace_floats, scores,
-                        save_for_backward != 0, nullptr, 0.f, (hipStream_t)stream);
+                        save_for_backward, nullptr, 0.f, (hipStream_t)stream);
 }
 // ---- single-state inference: the SCIP cut selector's call (model_evaluator.py:82-111) as ONE entry point --------------------
 static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -810,7 +831,7 @@ extern "C" int gcnn_infer(const gcnn_dims* d, const float* params, const void* h
     float* out = (float*)(A + L.dev_off[6]);
     // the plan's three steps ride in the forward pass's first three launches (k_infer.hpp)
     rc = forward_impl(d, params, (const float*)(A + L.in_off[1]), (const float*)(A + L.in_off[4]), (const float*)(A + L.in_off[5]),
-                      &cg, &kg, (float*)(A + L.dev_off[7]), gcnn_workspace_floats(d), out, false, nullptr, 0.f, st, &ia);
+                      &cg, &kg, (float*)(A + L.dev_off[7]), gcnn_workspace_floats(d), out, 0, nullptr, 0.f, st, &ia);
     if (rc) return rc;
     if (want_order && K > 0) {
         ProfScope prof("k_rank_scores", st);
@@ -844,7 +865,7 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
                       const float* cut_feats, const gcnn_graph* cg, const gcnn_graph* kg, float* workspace,
                       size_t workspace_floats, float* scores, const float* targets, float loss_scale, void* stream) {
     if (d && d->n_cuts > 0 && !targets) return GCNN_E_BADARG;
-    return forward_impl(d, p, cons_feats, var_feats, cut_feats, cg, kg, workspace, workspace_floats, scores, true,
+    return forward_impl(d, p, cons_feats, var_feats, cut_feats, cg, kg, workspace, workspace_floats, scores, 1,
                         d && d->n_cuts > 0 ? targets : nullptr, loss_scale, (hipStream_t)stream);
 }
 
@@ -855,6 +876,7 @@ struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
     DwRedArgs dw; int ndw;   // d w_edge pre-reductions (one per convolution with edge-gradient partials)
+    FoldArgs fold;           // convolutions whose folded-layer gradients k_fold_grads has to unfold
     PendWg pend[WG_MAX_JOBS]; int npend;   // weight-gradient jobs as collected; ordered and placed by place_wg
 };
 static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr,
@@ -936,8 +958,7 @@ static ConvBArgs conv_bwd_args(const float* p, const ConvIO& c, const float* in,
     a.in = in; a.w0 = w0; a.x_out = c.OUT; a.g_out = c.gOUT;
     a.w2 = p + poff(c.pbase + C_W2); a.z1 = c.Z1; a.g_z1 = c.gZ1;
     a.w1b = p + poff(c.pbase + C_W1) + EMB * EMB; a.g_xrecv = c.recv_left ? c.gXL : c.gXV;
-    a.w1a = p + poff(c.pbase + C_W1); a.s2 = p + poff(c.pbase + C_S2); a.g_a = c.gA;
-    a.wf = p + poff(c.pbase + C_WF); a.g_s = c.gS;
+    a.mfuse = c.FZ; a.g_s = c.gS;
     a.s1 = p + poff(c.pbase + C_S1); a.nrows = c.N; a.g_precv = c.recv_left ? c.gPL : c.gPR;
     return a;
 }
@@ -961,9 +982,17 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     }
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
     add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
-    add_wg(jl, c.A, p + poff(c.pbase + C_S2), c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1), grads + poff(c.pbase + C_B1), nullptr, w.partial);
+    // the folded layers: ONE product S^T dZ1 (-> G1) with the column sum (-> d b1) and the degree-weighted column sum (-> g2) of
+    // dZ1; k_fold_grads turns G1 | g2 into the gradients of Wf, bf and the upper half of W1 (the two-layer form needed A^T dZ1 and
+    // S^T dA: two products, and A and dA in memory)
+    if (nr > 0) {
+        add_wg(jl, c.S, nullptr, c.gZ1, seg, nr, c.GFZ, grads + poff(c.pbase + C_B1), c.GFZ + EMB * EMB, w.partial);
+        const int k = jl.fold.n++;
+        jl.fold.g1[k] = c.GFZ; jl.fold.wf[k] = p + poff(c.pbase + C_WF); jl.fold.bf[k] = p + poff(c.pbase + C_BF);
+        jl.fold.w1a[k] = p + poff(c.pbase + C_W1); jl.fold.s2[k] = p + poff(c.pbase + C_S2);
+        jl.fold.gwf[k] = grads + poff(c.pbase + C_WF); jl.fold.gbf[k] = grads + poff(c.pbase + C_BF); jl.fold.gw1a[k] = grads + poff(c.pbase + C_W1);
+    }
     add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
-    add_wg(jl, c.S, nullptr, c.gA, seg, nr, grads + poff(c.pbase + C_WF), nullptr, grads + poff(c.pbase + C_BF), w.partial);
     add_wg(jl, c.xl, nullptr, c.gPL, nullptr, c.nl, grads + poff(c.pbase + C_WL), grads + poff(c.pbase + C_BL), nullptr, w.partial);
     add_wg(jl, c.xv, nullptr, c.gPR, nullptr, c.nv, grads + poff(c.pbase + C_WR), nullptr, nullptr, w.partial);
     return 0;
@@ -1086,6 +1115,12 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     if (jl.rdblk > 0) {
         ProfScope prof(fuse_adam ? "k_reduce<adam>" : "k_reduce", st);
         hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
+        LAUNCHCHK();
+    }
+    if (jl.fold.n > 0) {   // G1 | g2 -> gradients of Wf, bf, W1a (with their Adam update when k_reduce carried everyone else's)
+        jl.fold.adam = jl.rd.adam;
+        ProfScope prof(fuse_adam ? "k_fold_grads<adam>" : "k_fold_grads", st);
+        hipLaunchKernelGGL(k_fold_grads, dim3(9 * jl.fold.n), dim3(256), 0, st, jl.fold);
         LAUNCHCHK();
     }
     return fuse_adam ? 0 : adam_after();

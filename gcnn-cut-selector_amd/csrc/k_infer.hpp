@@ -196,13 +196,15 @@ __global__ __launch_bounds__(NWAVES * 64) void k_infer_s1(EmbGroupArgs m, IplanA
         if (b < m.blk0[1]) emb_split<14, 2>(m.v, smem, b, m.blk0[1]);
         else if (b < m.blk0[2]) emb_split<4, 1>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
         else if (b < m.blk0[3]) emb_split<6, 1>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
-        else iplan_count_body(ia, b - m.blk0[3], NWAVES * 64);
+        else if (b < m.blk0[3] + 3) fuse_weights(m.fz, b - m.blk0[3], smem);
+        else iplan_count_body(ia, b - m.blk0[3] - 3, NWAVES * 64);
         return;
     }
     if (b < m.blk0[1]) emb_program<14, 2, NWAVES * 64>(m.v, smem, b, m.blk0[1]);
     else if (b < m.blk0[2]) emb_program<4, 1, NWAVES * 64>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
     else if (b < m.blk0[3]) emb_program<6, 1, NWAVES * 64>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
-    else iplan_count_body(ia, b - m.blk0[3], NWAVES * 64);
+    else if (b < m.blk0[3] + 3) fuse_weights(m.fz, b - m.blk0[3], smem);
+    else iplan_count_body(ia, b - m.blk0[3] - 3, NWAVES * 64);
 }
 template <bool BLOCKSEG>
 __global__ __launch_bounds__(256) void k_infer_s2(EdgeArgs e, IplanArgs ia, int edge_blocks) {
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_infer_s3(ConvFArgs a, IplanArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < conv_blocks) {
-        if (SPLIT) convf_split<CF_PROJ>(a, smem, b, conv_blocks);
+        if (SPLIT) convf_split<CF_PROJ>(a, smem, b, conv_blocks);   // (the folded form: inference never keeps A)
         else convf_program<CF_PROJ, NWAVES * 64>(a, smem, b, conv_blocks);
     }
     else iplan_order_body<NWAVES * 64>(ia, b - conv_blocks, gridDim.x - conv_blocks);

@@ -270,21 +270,67 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
         for (int f = 0; f < F; ++f) xv[f] = xn_[f];
     }
 }
-struct EmbGroupArgs { int blk0[4]; EmbArgs v, c, k; };   // variables (F=14, two projections), constraints (4), cuts (6)
+// The folded weights of the three convolutions (Program 2): M = s2 * Wf * W1a [64,64] followed by u = s2 * bf * W1a [64], FUSE_FLOATS
+// floats per convolution.  One 256-thread block each, riding in the embedding launch (the first consumer is the third launch
+// of a forward pass); exact fp32 FMA chains in k order.  smem: 2 * 64 * LDW floats.
+#define FUSE_FLOATS (EMB * EMB + EMB)
+struct FuseArgs { const float *wf[3], *bf[3], *s2[3], *w1a[3]; float* out[3]; };
+__device__ __forceinline__ void fuse_weights(const FuseArgs& f, const int k, float* smem) {
+    float* wfs = smem;                  // Wf  [i][LDW]
+    float* was = smem + 64 * LDW;       // W1a [j][LDW]
+    const int t = threadIdx.x;
+    if (t < 256) {
+        for (int q = t; q < 1024; q += 256) {
+            *(float4*)(wfs + (q >> 4) * LDW + (q & 15) * 4) = *(const float4*)(f.wf[k] + q * 4);
+            *(float4*)(was + (q >> 4) * LDW + (q & 15) * 4) = *(const float4*)(f.w1a[k] + q * 4);
+        }
+    }
+    __syncthreads();
+    if (t >= 256) return;
+    const float s2 = *f.s2[k];
+    const int i0 = (t >> 4) * 4, o0 = (t & 15) * 4;   // a 4 x 4 block of M per thread
+    float acc[4][4] = {};
+    for (int j = 0; j < EMB; ++j) {
+        const float4 w = *(const float4*)(was + j * LDW + o0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = wfs[(i0 + r) * LDW + j];
+            acc[r][0] = fmaf(a, w.x, acc[r][0]); acc[r][1] = fmaf(a, w.y, acc[r][1]);
+            acc[r][2] = fmaf(a, w.z, acc[r][2]); acc[r][3] = fmaf(a, w.w, acc[r][3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        *(float4*)(f.out[k] + (i0 + r) * EMB + o0) = make_float4(s2 * acc[r][0], s2 * acc[r][1], s2 * acc[r][2], s2 * acc[r][3]);
+    if (t < EMB) {
+        float u = 0.f;
+        for (int j = 0; j < EMB; ++j) u = fmaf(f.bf[k][j], was[j * LDW + t], u);
+        f.out[k][EMB * EMB + t] = s2 * u;
+    }
+}
+struct EmbGroupArgs { int blk0[4]; EmbArgs v, c, k; FuseArgs fz; };   // variables (F=14, two projections), constraints (4), cuts (6); blocks blk0[3] .. +2: fuse_weights
 #define EMB_LDS_FLOATS (ROWS_LDS_FLOATS(3, 4) + 14 * 64)
+static_assert(EMB_LDS_FLOATS >= 2 * 64 * LDW, "fuse_weights stages two matrices in the embedding launch's LDS");
 template <int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < m.blk0[1]) emb_program<14, 2, NWAVES * 64>(m.v, smem, b, m.blk0[1]);
     else if (b < m.blk0[2]) emb_program<4, 1, NWAVES * 64>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
-    else emb_program<6, 1, NWAVES * 64>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
+    else if (b < m.blk0[3]) emb_program<6, 1, NWAVES * 64>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
+    else fuse_weights(m.fz, b - m.blk0[3], smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Program 2 (forward): receiver-side update of a PartialGraphConvolution after the edge pass (model.py:498-508, 568-573)
-//   A  = S Wf + deg_r bf                 (the per-edge Dense hoisted past the scatter-sum)        -> a_out (optional)
+//   A  = S Wf + deg_r bf                 (the per-edge Dense hoisted past the scatter-sum)
 //   Z1 = relu([s2*A | x_recv] W1 + b1)                                                             -> z1 (optional)
+//        Nothing lies between the two layers but the PreNorm scale s2, so they are ONE product with the folded matrix
+//        M = s2*Wf*W1a and vector u = s2*bf*W1a (made once per forward by fuse_weights, riding in the embedding launch):
+//          Z1 = relu(S M + deg_r u + x_recv W1b + b1)
+//        -- a 64x64 product per receiver row less, and A is neither written nor read again (the backward pass folds the same
+//        way: dS = dZ1 M^T; the gradients of Wf, bf and W1a come out of S^T dZ1, see k_fold_grads).  KEEP_A = true is the
+//        two-layer form that materialises A: PreNorm fitting needs its statistics (model.py:503, 570).
 //   X' = relu(Z1 W2 + b2)                                                                          -> out
 //   TAIL = CF_PROJ   :  T = X' Wt (+ bt): the next convolution's projection                        -> t_out
 //   TAIL = CF_READOUT:  O1 = relu(X' Wt + bt) -> o1 (optional);  score = O1 . ws + bs (model.py:206-208) -> scores
@@ -294,7 +340,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
 //                         per-tile partials {dws = sum_k ds_k O1[k], dbs = sum_k ds_k, loss = scale*sum_k d_k^2} -> head_partial
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvFArgs {
-    const float* s; const int* seg_ptr; const float *wf, *bf; float* a_out;
+    const float* s; const int* seg_ptr; const float *wf, *bf; float* a_out;     // wf, bf, a_out, s2, w1a: the KEEP_A form only
+    const float *mfuse, *ufuse;                                                    // M = s2*Wf*W1a [64,64], u = s2*bf*W1a [64] (k_fuse)
     const float *s2, *xrecv, *w1a, *w1b, *b1; float* z1;
     const float *w2, *b2; float* out;
     const float *wt, *bt; float* t_out;      // readout: wt/bt = readout Dense(64,relu), t_out = O1
@@ -347,9 +394,10 @@ __device__ __forceinline__ void loss_head_tile(RTile& go, const RTile& o1, float
     const float dbs = row_sum16(ds), ls = row_sum16(a.loss_scale * dlt * dlt);
     if (lane == 0) { slab[EMB] = dbs; slab[EMB + 1] = ls; }
 }
-template <int TAIL, int NT>
+template <int TAIL, int NT, bool KEEP_A = false>
 __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, int bid, int nblk) {
-    constexpr int NWAVES = NT / 64, NM = 5, NV = 5;   // Wf W1a W1b W2 Wt | bf b1 b2 bt ws
+    constexpr int NWAVES = NT / 64, NM = KEEP_A ? 5 : 4, NV = 5;   // [Wf W1a | M] W1b W2 Wt | [bf | u] b1 b2 bt ws
+    constexpr int iW1B = NM - 3, iW2 = NM - 2, iWT = NM - 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
@@ -363,12 +411,16 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
         d.seg0 = ok ? a.seg_ptr[row] : 0; d.seg1 = ok ? a.seg_ptr[row + 1] : 0;
     };
     load_ops(cur, tile);
-    {
+    if (KEEP_A) {
         const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
         const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, TAIL != CF_PROJ ? a.ws : nullptr};
         stage_lds<5, 5, NT, true>(smem, w, v);
+    } else {
+        const float* const w[4] = {a.mfuse, a.w1b, a.w2, a.wt};
+        const float* const v[5] = {a.ufuse, a.b1, a.b2, a.bt, TAIL != CF_PROJ ? a.ws : nullptr};
+        stage_lds<4, 5, NT, true>(smem, w, v);
     }
-    const float s2 = *a.s2;
+    const float s2 = KEEP_A ? *a.s2 : 1.f;
     const float bs = TAIL != CF_PROJ ? *a.bs : 0.f;
     __syncthreads();
     for (; tile < ntile; tile += nblk * NWAVES) {
@@ -377,28 +429,34 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;
-        rt_mm<false>(t0, s_in, 1.f, smem, lane);
-        {   // + deg * bf
+        auto add_deg = [&](RTile& t) {   // + deg * (bf | u)
             const float deg = (float)(cur.seg1 - cur.seg0);
             const float* bfv = lds_here(vecs);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float4 b = *(const float4*)(bfv + 16 * m + 4 * g);
-                t0.v[m][0] = fmaf(deg, b.x, t0.v[m][0]); t0.v[m][1] = fmaf(deg, b.y, t0.v[m][1]);
-                t0.v[m][2] = fmaf(deg, b.z, t0.v[m][2]); t0.v[m][3] = fmaf(deg, b.w, t0.v[m][3]);
+                t.v[m][0] = fmaf(deg, b.x, t.v[m][0]); t.v[m][1] = fmaf(deg, b.y, t.v[m][1]);
+                t.v[m][2] = fmaf(deg, b.z, t.v[m][2]); t.v[m][3] = fmaf(deg, b.w, t.v[m][3]);
             }
+        };
+        if (KEEP_A) {
+            rt_mm<false>(t0, s_in, 1.f, smem, lane);
+            add_deg(t0);
+            rt_clear_unless(t0, ok);
+            rt_store(t0, a.a_out, row, ok, g);
+            rt_mm2<false>(t1, t0, s2, smem + 64 * LDW, xr, smem + 2 * 64 * LDW, lane);
+        } else {
+            rt_mm2<false>(t1, s_in, 1.f, smem, xr, smem + iW1B * 64 * LDW, lane);
+            add_deg(t1);
         }
-        rt_clear_unless(t0, ok);
-        rt_store(t0, a.a_out, row, ok, g);
-        rt_mm2<false>(t1, t0, s2, smem + 64 * LDW, xr, smem + 2 * 64 * LDW, lane);
         rt_bias<true>(t1, vecs + 64, g);
         rt_clear_unless(t1, ok);
         rt_store(t1, a.z1, row, ok, g);
-        rt_mm<false>(t0, t1, 1.f, smem + 3 * 64 * LDW, lane);
+        rt_mm<false>(t0, t1, 1.f, smem + iW2 * 64 * LDW, lane);
         rt_bias<true>(t0, vecs + 2 * 64, g);
         rt_clear_unless(t0, ok);
         rt_store(t0, a.out, row, ok, g);
-        rt_mm<false>(t1, t0, 1.f, smem + 4 * 64 * LDW, lane);
+        rt_mm<false>(t1, t0, 1.f, smem + iWT * 64 * LDW, lane);
         if (TAIL == CF_PROJ) {
             rt_bias<false>(t1, vecs + 3 * 64, g);
             rt_store(t1, a.t_out, row, ok, g);
@@ -417,10 +475,10 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
         cur = nxt;
     }
 }
-template <int NWAVES, int TAIL>
+template <int NWAVES, int TAIL, bool KEEP_A = false>
 __global__ __launch_bounds__(NWAVES * 64) void k_conv_fwd(ConvFArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    convf_program<TAIL, NWAVES * 64>(a, smem, blockIdx.x, gridDim.x);
+    convf_program<TAIL, NWAVES * 64, KEEP_A>(a, smem, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -429,16 +487,14 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_fwd(ConvFArgs a) {
 //   dX'  = (in W0^T) * (X' > 0)                                              -> g_out
 //   dZ1  = (dX' W2^T) * (Z1 > 0)                                             -> g_z1
 //   dx_r = dZ1 W1b^T                                                         -> g_xrecv
-//   dA   = s2 * (dZ1 W1a^T)                                                  -> g_a
-//   dS   = dA Wf^T                                                           -> g_s
+//   dS   = dZ1 M^T          (= s2 * (dZ1 W1a^T) Wf^T with the folded matrix of Program 2)   -> g_s
 //   dP_recv = s1 * dS * N   (receiver-ordered half of the edge gradient, see k_edge_fwd)   -> g_precv
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvBArgs {
     const float *in, *w0, *x_out; float* g_out;
     const float *w2, *z1; float* g_z1;
     const float* w1b; float* g_xrecv;
-    const float *w1a, *s2; float* g_a;
-    const float* wf; float* g_s;
+    const float* mfuse; float* g_s;
     const float *s1, *nrows; float* g_precv;
     int n;
 };
@@ -459,11 +515,11 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
     };
     load_ops(cur, tile);
     {
-        const float* const w[5] = {a.w0, a.w2, a.w1b, a.w1a, a.wf};
+        const float* const w[4] = {a.w0, a.w2, a.w1b, a.mfuse};
         const float* const v[1] = {nullptr};
-        stage_lds<5, 1, NT>(smem, w, v);
+        stage_lds<4, 1, NT>(smem, w, v);
     }
-    const float s2 = *a.s2, s1 = *a.s1;
+    const float s1 = *a.s1;
     __syncthreads();
     for (; tile < ntile; tile += nblk * NWAVES) {
         load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
@@ -480,18 +536,12 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
         rt_mm<true>(t0, t1, 1.f, smem + 2 * 64 * LDW, lane);
         rt_store(t0, a.g_xrecv, row, ok, g);
         rt_mm<true>(t0, t1, 1.f, smem + 3 * 64 * LDW, lane);
+        rt_store(t0, a.g_s, row, ok, g);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t0.v[m][i] *= s2;
-        rt_store(t0, a.g_a, row, ok, g);
-        rt_mm<true>(t1, t0, 1.f, smem + 4 * 64 * LDW, lane);
-        rt_store(t1, a.g_s, row, ok, g);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t1.v[m][i] = s1 * t1.v[m][i] * nr.v[m][i];
-        rt_store(t1, a.g_precv, row, ok, g);
+            for (int i = 0; i < 4; ++i) t0.v[m][i] = s1 * t0.v[m][i] * nr.v[m][i];
+        rt_store(t0, a.g_precv, row, ok, g);
         cur = nxt;
     }
 }
@@ -502,13 +552,13 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
 // row-local on the same tiles with nothing between them, so a training step runs them as ONE program: the activations the
 // backward half masks with (X', Z1, O1) and its input gradient dO1pre never leave the registers, and the step has one launch
 // (and one weight staging) less.  Every tensor the weight-gradient launch or the edge passes read is still stored.
-// The five matrices serve both directions, so they are staged once, row-major: the forward products read them with
-// rt_gemm<GEMM_FWD_RM>, the backward products as float4 (two stagings would not fit the LDS).
+// The four matrices serve both directions, so they are staged once, row-major: the forward products read them with
+// rt_gemm<GEMM_FWD_RM>, the backward products as float4.
 //   f: as convf_program<CF_LOSS>;  b: as convb_program with in = f.g_o1, w0 = f.wt, x_out = f.out, z1 = f.z1 (not re-read)
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void convturn_program(const ConvFArgs& a, const ConvBArgs& b, float* smem, int bid, int nblk) {
-    constexpr int NWAVES = NT / 64, NM = 5;   // Wf W1a W1b W2 Wt | bf b1 b2 bt ws
+    constexpr int NWAVES = NT / 64, NM = 4;   // M W1b W2 Wt | u b1 b2 bt ws
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
@@ -524,13 +574,13 @@ __device__ __forceinline__ void convturn_program(const ConvFArgs& a, const ConvB
     };
     load_ops(cur, tile);
     {
-        const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
-        const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, a.ws};
-        stage_lds<5, 5, NT>(smem, w, v);
+        const float* const w[4] = {a.mfuse, a.w1b, a.w2, a.wt};
+        const float* const v[5] = {a.ufuse, a.b1, a.b2, a.bt, a.ws};
+        stage_lds<4, 5, NT>(smem, w, v);
     }
-    const float s2 = *a.s2, s1 = *b.s1, bs = *a.bs;
-    float* const WF = smem; float* const W1A = smem + 64 * LDW; float* const W1B = smem + 2 * 64 * LDW;
-    float* const W2 = smem + 3 * 64 * LDW; float* const WT = smem + 4 * 64 * LDW;
+    const float s1 = *b.s1, bs = *a.bs;
+    float* const MF = smem; float* const W1B = smem + 64 * LDW;
+    float* const W2 = smem + 2 * 64 * LDW; float* const WT = smem + 3 * 64 * LDW;
     __syncthreads();
     for (; tile < ntile; tile += nblk * NWAVES) {
         load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
@@ -538,20 +588,17 @@ __device__ __forceinline__ void convturn_program(const ConvFArgs& a, const ConvB
         const bool ok = row < a.n;
         RTile t0, z1, xo, t1;
         // ---- forward half (convf_program<CF_LOSS>)
-        rt_mm<GEMM_FWD_RM>(t0, cur.s_in, 1.f, WF, lane);
-        {   // + deg * bf
+        rt_mm2<GEMM_FWD_RM>(z1, cur.s_in, 1.f, MF, cur.xr, W1B, lane);
+        {   // + deg * u
             const float deg = (float)(cur.seg1 - cur.seg0);
             const float* bfv = lds_here(vecs);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float4 bb = *(const float4*)(bfv + 16 * m + 4 * g);
-                t0.v[m][0] = fmaf(deg, bb.x, t0.v[m][0]); t0.v[m][1] = fmaf(deg, bb.y, t0.v[m][1]);
-                t0.v[m][2] = fmaf(deg, bb.z, t0.v[m][2]); t0.v[m][3] = fmaf(deg, bb.w, t0.v[m][3]);
+                z1.v[m][0] = fmaf(deg, bb.x, z1.v[m][0]); z1.v[m][1] = fmaf(deg, bb.y, z1.v[m][1]);
+                z1.v[m][2] = fmaf(deg, bb.z, z1.v[m][2]); z1.v[m][3] = fmaf(deg, bb.w, z1.v[m][3]);
             }
         }
-        rt_clear_unless(t0, ok);
-        rt_store(t0, a.a_out, row, ok, g);
-        rt_mm2<GEMM_FWD_RM>(z1, t0, s2, W1A, cur.xr, W1B, lane);
         rt_bias<true>(z1, vecs + 64, g);
         rt_clear_unless(z1, ok);
         rt_store(z1, a.z1, row, ok, g);
@@ -576,19 +623,13 @@ __device__ __forceinline__ void convturn_program(const ConvFArgs& a, const ConvB
         rt_store(t0, b.g_z1, row, ok, g);
         rt_mm<GEMM_BWD>(t1, t0, 1.f, W1B, lane);
         rt_store(t1, b.g_xrecv, row, ok, g);
-        rt_mm<GEMM_BWD>(t1, t0, 1.f, W1A, lane);
+        rt_mm<GEMM_BWD>(t1, t0, 1.f, MF, lane);
+        rt_store(t1, b.g_s, row, ok, g);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t1.v[m][i] *= s2;
-        rt_store(t1, b.g_a, row, ok, g);
-        rt_mm<GEMM_BWD>(t0, t1, 1.f, WF, lane);
-        rt_store(t0, b.g_s, row, ok, g);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) t0.v[m][i] = s1 * t0.v[m][i] * cur.nr.v[m][i];
-        rt_store(t0, b.g_precv, row, ok, g);
+            for (int i = 0; i < 4; ++i) t1.v[m][i] = s1 * t1.v[m][i] * cur.nr.v[m][i];
+        rt_store(t1, b.g_precv, row, ok, g);
         cur = nxt;
     }
 }

@@ -149,19 +149,24 @@ __device__ __forceinline__ void emb_split(const EmbArgs& a, float* smem, int bid
 }
 
 // ---- Program 2, split: receiver-side update (convf_program; CF_PROJ and CF_READOUT -- the training tail is convturn_split) ----
-template <int TAIL>
+template <int TAIL, bool KEEP_A = false>
 __device__ __forceinline__ void convf_split(const ConvFArgs& a, float* smem, int bid, int nblk) {
     static_assert(TAIL == CF_PROJ || TAIL == CF_READOUT, "the loss tail runs in convturn_split");
-    constexpr int NT = 256, NM = 5;
+    constexpr int NT = 256, NM = KEEP_A ? 5 : 4;
+    constexpr int iW1B = NM - 3, iW2 = NM - 2, iWT = NM - 1;
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
-    SplitLane L(smem + ROWS_LDS_FLOATS(5, 5));
-    {
+    SplitLane L(smem + ROWS_LDS_FLOATS(5, 5));   // the exchange tiles sit behind the larger (KEEP_A) image in either form
+    if (KEEP_A) {
         const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
         const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, TAIL != CF_PROJ ? a.ws : nullptr};
         stage_lds<5, 5, NT, true>(smem, w, v);
+    } else {
+        const float* const w[4] = {a.mfuse, a.w1b, a.w2, a.wt};
+        const float* const v[5] = {a.ufuse, a.b1, a.b2, a.bt, TAIL != CF_PROJ ? a.ws : nullptr};
+        stage_lds<4, 5, NT, true>(smem, w, v);
     }
-    const float s2 = *a.s2;
+    const float s2 = KEEP_A ? *a.s2 : 1.f;
     const float bs = TAIL != CF_PROJ ? *a.bs : 0.f;
     __syncthreads();
     for (int tile = bid; tile < ntile; tile += nblk) {
@@ -172,25 +177,31 @@ __device__ __forceinline__ void convf_split(const ConvFArgs& a, float* smem, int
         rt_load(xr, a.xrecv, row, ok, L.g);
         const float deg = ok ? (float)(a.seg_ptr[row + 1] - a.seg_ptr[row]) : 0.f;
         RQuart q;
-        rq_mm<GEMM_FWD>(q, s_in, 1.f, smem, L);
-        {   // + deg * bf
+        auto add_deg = [&](RQuart& t) {   // + deg * (bf | u)
             const float4 b = *(const float4*)(lds_here(vecs) + 16 * L.wv + 4 * L.g);
-            q.v[0] = fmaf(deg, b.x, q.v[0]); q.v[1] = fmaf(deg, b.y, q.v[1]); q.v[2] = fmaf(deg, b.z, q.v[2]); q.v[3] = fmaf(deg, b.w, q.v[3]);
+            t.v[0] = fmaf(deg, b.x, t.v[0]); t.v[1] = fmaf(deg, b.y, t.v[1]); t.v[2] = fmaf(deg, b.z, t.v[2]); t.v[3] = fmaf(deg, b.w, t.v[3]);
+        };
+        if (KEEP_A) {
+            rq_mm<GEMM_FWD>(q, s_in, 1.f, smem, L);
+            add_deg(q);
+            rq_clear_unless(q, ok);
+            rq_store(q, a.a_out, row, ok, L);
+            rq_exchange(full, q, L);
+            rq_mm2<GEMM_FWD>(q, full, s2, smem + 64 * LDW, xr, smem + 2 * 64 * LDW, L);
+        } else {
+            rq_mm2<GEMM_FWD>(q, s_in, 1.f, smem, xr, smem + iW1B * 64 * LDW, L);
+            add_deg(q);
         }
-        rq_clear_unless(q, ok);
-        rq_store(q, a.a_out, row, ok, L);
-        rq_exchange(full, q, L);
-        rq_mm2<GEMM_FWD>(q, full, s2, smem + 64 * LDW, xr, smem + 2 * 64 * LDW, L);
         rq_bias<true>(q, vecs + 64, L);
         rq_clear_unless(q, ok);
         rq_store(q, a.z1, row, ok, L);
         rq_exchange(z, q, L);
-        rq_mm<GEMM_FWD>(q, z, 1.f, smem + 3 * 64 * LDW, L);
+        rq_mm<GEMM_FWD>(q, z, 1.f, smem + iW2 * 64 * LDW, L);
         rq_bias<true>(q, vecs + 2 * 64, L);
         rq_clear_unless(q, ok);
         rq_store(q, a.out, row, ok, L);
         rq_exchange(full, q, L);
-        rq_mm<GEMM_FWD>(q, full, 1.f, smem + 4 * 64 * LDW, L);
+        rq_mm<GEMM_FWD>(q, full, 1.f, smem + iWT * 64 * LDW, L);
         if (TAIL == CF_PROJ) {
             rq_bias<false>(q, vecs + 3 * 64, L);
             rq_store(q, a.t_out, row, ok, L);
@@ -209,18 +220,18 @@ __device__ __forceinline__ void convf_split(const ConvFArgs& a, float* smem, int
 
 // ---- Program 2+3, split: the training turnaround of the cut rows (convturn_program) -----------------------------------------
 __device__ __forceinline__ void convturn_split(const ConvFArgs& a, const ConvBArgs& b, float* smem, int bid, int nblk) {
-    constexpr int NT = 256, NM = 5;
+    constexpr int NT = 256, NM = 4;
     const int ntile = (a.n + 15) >> 4;
     float* vecs = smem + NM * 64 * LDW;
     SplitLane L(smem + ROWS_LDS_FLOATS(5, 5));
     {
-        const float* const w[5] = {a.wf, a.w1a, a.w1b, a.w2, a.wt};
-        const float* const v[5] = {a.bf, a.b1, a.b2, a.bt, a.ws};
-        stage_lds<5, 5, NT>(smem, w, v);
+        const float* const w[4] = {a.mfuse, a.w1b, a.w2, a.wt};
+        const float* const v[5] = {a.ufuse, a.b1, a.b2, a.bt, a.ws};
+        stage_lds<4, 5, NT>(smem, w, v);
     }
-    const float s2 = *a.s2, s1 = *b.s1, bs = *a.bs;
-    float* const WF = smem; float* const W1A = smem + 64 * LDW; float* const W1B = smem + 2 * 64 * LDW;
-    float* const W2 = smem + 3 * 64 * LDW; float* const WT = smem + 4 * 64 * LDW;
+    const float s1 = *b.s1, bs = *a.bs;
+    float* const MF = smem; float* const W1B = smem + 64 * LDW;
+    float* const W2 = smem + 2 * 64 * LDW; float* const WT = smem + 3 * 64 * LDW;
     __syncthreads();
     for (int tile = bid; tile < ntile; tile += nblk) {
         const int row = tile * 16 + L.j;
@@ -232,15 +243,11 @@ __device__ __forceinline__ void convturn_split(const ConvFArgs& a, const ConvBAr
         rq_load(nr, b.nrows, row, ok, L);
         const float deg = ok ? (float)(a.seg_ptr[row + 1] - a.seg_ptr[row]) : 0.f;
         // ---- forward half
-        rq_mm<GEMM_FWD_RM>(q, s_in, 1.f, WF, L);
+        rq_mm2<GEMM_FWD_RM>(z1q, s_in, 1.f, MF, xr, W1B, L);
         {
             const float4 bb = *(const float4*)(lds_here(vecs) + 16 * L.wv + 4 * L.g);
-            q.v[0] = fmaf(deg, bb.x, q.v[0]); q.v[1] = fmaf(deg, bb.y, q.v[1]); q.v[2] = fmaf(deg, bb.z, q.v[2]); q.v[3] = fmaf(deg, bb.w, q.v[3]);
+            z1q.v[0] = fmaf(deg, bb.x, z1q.v[0]); z1q.v[1] = fmaf(deg, bb.y, z1q.v[1]); z1q.v[2] = fmaf(deg, bb.z, z1q.v[2]); z1q.v[3] = fmaf(deg, bb.w, z1q.v[3]);
         }
-        rq_clear_unless(q, ok);
-        rq_store(q, a.a_out, row, ok, L);
-        rq_exchange(full, q, L);
-        rq_mm2<GEMM_FWD_RM>(z1q, full, s2, W1A, xr, W1B, L);
         rq_bias<true>(z1q, vecs + 64, L);
         rq_clear_unless(z1q, ok);
         rq_store(z1q, a.z1, row, ok, L);
@@ -285,12 +292,7 @@ __device__ __forceinline__ void convturn_split(const ConvFArgs& a, const ConvBAr
         rq_exchange(full, q, L);
         rq_mm<GEMM_BWD>(q, full, 1.f, W1B, L);
         rq_store(q, b.g_xrecv, row, ok, L);
-        rq_mm<GEMM_BWD>(q, full, 1.f, W1A, L);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q.v[i] *= s2;
-        rq_store(q, b.g_a, row, ok, L);
-        rq_exchange(full, q, L);
-        rq_mm<GEMM_BWD>(q, full, 1.f, WF, L);
+        rq_mm<GEMM_BWD>(q, full, 1.f, MF, L);
         rq_store(q, b.g_s, row, ok, L);
 #pragma unroll
         for (int i = 0; i < 4; ++i) q.v[i] = s1 * q.v[i] * nr.v[i];
@@ -301,17 +303,18 @@ __global__ __launch_bounds__(256) void k_conv_turn_split(ConvFArgs f, ConvBArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     convturn_split(f, b, smem, blockIdx.x, gridDim.x);
 }
-template <int TAIL>
+template <int TAIL, bool KEEP_A = false>
 __global__ __launch_bounds__(256) void k_conv_fwd_split(ConvFArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    convf_split<TAIL>(a, smem, blockIdx.x, gridDim.x);
+    convf_split<TAIL, KEEP_A>(a, smem, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void k_embed_fwd_split(EmbGroupArgs m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < m.blk0[1]) emb_split<14, 2>(m.v, smem, b, m.blk0[1]);
     else if (b < m.blk0[2]) emb_split<4, 1>(m.c, smem, b - m.blk0[1], m.blk0[2] - m.blk0[1]);
-    else emb_split<6, 1>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
+    else if (b < m.blk0[3]) emb_split<6, 1>(m.k, smem, b - m.blk0[2], m.blk0[3] - m.blk0[2]);
+    else fuse_weights(m.fz, b - m.blk0[3], smem);
 }
 #define EMB_SPLIT_LDS_FLOATS (EMB_LDS_FLOATS + SX_FLOATS)
 #define CONV_SPLIT_LDS_FLOATS (ROWS_LDS_FLOATS(5, 5) + SX_FLOATS)

@@ -240,3 +240,56 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gradients of the folded layers (k_rows.hpp, Program 2): the forward uses M = s2*Wf*W1a and u = s2*bf*W1a, the weight-gradient
+// launch leaves, per convolution, G1 = S^T dZ1 [64,64] and g2 = sum_r deg_r dZ1[r] [64] (one job instead of the two that needed
+// A and dA).  By the chain rule through M and u:
+//   dWf  = s2 * G1 W1a^T          dW1a = s2 * (Wf^T G1 + bf (x) g2)          dbf = s2 * W1a g2
+// A few 64^3 products on reduced data: 9 blocks per convolution (four 16-row slices of dWf, four of dW1a, one for dbf), straight
+// from global memory (everything is L2-resident), fixed summation order; carries the Adam update of these entries when the
+// backward pass was asked to apply it (k_reduce does the same for every other gradient).
+// ---------------------------------------------------------------------------------------------------------------
+struct FoldArgs { const float *g1[3], *wf[3], *bf[3], *w1a[3], *s2[3]; float *gwf[3], *gbf[3], *gw1a[3]; int n; RdAdam adam; };
+__global__ __launch_bounds__(256) void k_fold_grads(FoldArgs a) {
+    const int c = blockIdx.x / 9, part = blockIdx.x % 9, t = threadIdx.x;
+    const float s2 = *a.s2[c];
+    const float *g1 = a.g1[c], *g2 = a.g1[c] + EMB * EMB, *wf = a.wf[c], *w1a = a.w1a[c], *bf = a.bf[c];
+    auto emit = [&](float* dst, float gi) {
+        *dst = gi;
+        const long long idx = dst - a.adam.gbase;
+        if (a.adam.p && idx >= 0 && idx < a.adam.gn) {
+            const float mi = a.adam.b1 * a.adam.m[idx] + (1.f - a.adam.b1) * gi;
+            const float vi = a.adam.b2 * a.adam.v[idx] + (1.f - a.adam.b2) * gi * gi;
+            a.adam.m[idx] = mi; a.adam.v[idx] = vi;
+            a.adam.p[idx] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
+        }
+    };
+    if (part < 4) {            // dWf[i][j] = s2 * sum_k G1[i][k] * W1a[j][k]
+        const int i = 16 * part + (t >> 4), j0 = (t & 15) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < EMB; ++k) {
+            const float g = g1[i * EMB + k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(g, w1a[(j0 + q) * EMB + k], acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) emit(a.gwf[c] + i * EMB + j0 + q, s2 * acc[q]);
+    } else if (part < 8) {     // dW1a[j][k] = s2 * (sum_i Wf[i][j] * G1[i][k] + bf[j] * g2[k])
+        const int j = 16 * (part - 4) + (t >> 4), k0 = (t & 15) * 4;
+        const float4 gg = *(const float4*)(g2 + k0);
+        const float b = bf[j];
+        float acc[4] = {b * gg.x, b * gg.y, b * gg.z, b * gg.w};
+        for (int i = 0; i < EMB; ++i) {
+            const float w = wf[i * EMB + j];
+            const float4 g = *(const float4*)(g1 + i * EMB + k0);
+            acc[0] = fmaf(w, g.x, acc[0]); acc[1] = fmaf(w, g.y, acc[1]); acc[2] = fmaf(w, g.z, acc[2]); acc[3] = fmaf(w, g.w, acc[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) emit(a.gw1a[c] + j * EMB + k0 + q, s2 * acc[q]);
+    } else if (t < EMB) {      // dbf[j] = s2 * sum_k W1a[j][k] * g2[k]
+        float acc = 0.f;
+        for (int k = 0; k < EMB; ++k) acc = fmaf(w1a[t * EMB + k], g2[k], acc);
+        emit(a.gbf[c] + t, s2 * acc);
+    }
+}

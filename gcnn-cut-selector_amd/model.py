@@ -518,7 +518,7 @@ class GCNN:
         ws = self._take_workspace(batch)
         flat = self._flat.detach()
         if layer >= 5:
-            self._forward_into(flat, batch, ws, save=True)
+            self._forward_into(flat, batch, ws, save=2)   # 2: the two-layer form that materialises A (the post-conv PreNorm's input)
         out = torch.empty(2 * units, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().gcnn_prenorm_stats(C.byref(batch.dims), _ptr(flat), _ptr(batch.cons_feats),

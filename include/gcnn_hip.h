@@ -144,8 +144,12 @@ int gcnn_conv_edge_bwd_send(const int32_t* seg_ptr, const int32_t* oth, const fl
 
 /* ---- whole-model forward: GCNN.call, model.py:257-300 ------------------------------------------------------
  * params: flat buffer (layout above).  cons/var/cut feats: [C,4], [V,14], [K,6] raw features (PreNorm applied
- * inside, model.py:365-382).  workspace: gcnn_workspace_floats(dims) floats.  save_for_backward != 0 leaves the
+ * inside, model.py:365-382).  workspace: gcnn_workspace_floats(dims) floats.  save_for_backward = 1 leaves the
  * activations and edge statistics (the N rows) gcnn_backward needs in the workspace; 0 (inference) skips those stores.
+ * The per-edge Dense (feature_module_final, model.py:499-500) and the upper half of output_module's first layer (model.py:505)
+ * have nothing between them but the PreNorm scale (model.py:503), so the pass multiplies by their product
+ * M = s2*Wf*W1a (made once per call); save_for_backward = 2 runs the two-layer form instead and also stores the tensor between
+ * them (the scatter-sum output A = post_conv_module's input) -- what gcnn_prenorm_stats reads for layers 6, 8 and 10.
  * scores: [n_cuts] (model.py:300). */
 size_t gcnn_workspace_floats(const gcnn_dims* dims);
 int gcnn_forward(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
@@ -227,7 +231,7 @@ int gcnn_backward(const gcnn_dims* dims, const float* params, const float* cons_
  * For ONE batch and ONE of the 11 PreNorm layers (call order: 0 cons, 1 cons-edge, 2 var, 3 cut, 4 cut-edge, then
  * 5+2k / 6+2k = feature_module_final / post_conv_module of convolution k) writes the population mean [units] followed by
  * the mean squared deviation [units] of that layer's input to out_mean_var (device doubles; units = 4,1,14,6,1 for the
- * input layers, 1 otherwise).  Layers >= 5 read activations of a preceding gcnn_forward(save_for_backward=1) on the same
+ * input layers, 1 otherwise).  Layers >= 5 read activations of a preceding gcnn_forward(save_for_backward=2) on the same
  * workspace, inputs and parameters.  The streaming merge over batches (Chan et al.) is the caller's, as in the reference. */
 int gcnn_prenorm_stats(const gcnn_dims* dims, const float* params, const float* cons_feats, const float* var_feats,
                        const float* cut_feats, const gcnn_graph* cons_graph, const gcnn_graph* cut_graph,
