@@ -252,9 +252,26 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 struct FoldArgs { const float *g1[3], *wf[3], *bf[3], *w1a[3], *s2[3]; float *gwf[3], *gbf[3], *gw1a[3]; int n; RdAdam adam; };
 __global__ __launch_bounds__(256) void k_fold_grads(FoldArgs a) {
+    // G1 and the one weight matrix a block needs go through LDS, every global load issued before the first LDS write: one memory
+    // round trip per block (read in the loops below, the same 64 dependent L2 round trips made the launch 13 us long)
+    __shared__ __attribute__((aligned(16))) float sg[EMB * LDW], sw[EMB * LDW], sv[2 * EMB];
     const int c = blockIdx.x / 9, part = blockIdx.x % 9, t = threadIdx.x;
     const float s2 = *a.s2[c];
-    const float *g1 = a.g1[c], *g2 = a.g1[c] + EMB * EMB, *wf = a.wf[c], *w1a = a.w1a[c], *bf = a.bf[c];
+    const float* wsrc = (part >= 4 && part < 8) ? a.wf[c] : a.w1a[c];
+    float4 tg[4], tw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { tg[q] = *(const float4*)(a.g1[c] + (q * 256 + t) * 4); tw[q] = *(const float4*)(wsrc + (q * 256 + t) * 4); }
+    const float vg = t < EMB ? a.g1[c][EMB * EMB + t] : (t < 2 * EMB ? a.bf[c][t - EMB] : 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = q * 256 + t, r = idx >> 4, col = (idx & 15) * 4;
+        *(float4*)(sg + r * LDW + col) = tg[q];
+        if (part < 4) {   // W1a transposed ([k][j]): the loop below reads four consecutive j per thread
+            sw[(col + 0) * LDW + r] = tw[q].x; sw[(col + 1) * LDW + r] = tw[q].y; sw[(col + 2) * LDW + r] = tw[q].z; sw[(col + 3) * LDW + r] = tw[q].w;
+        } else *(float4*)(sw + r * LDW + col) = tw[q];
+    }
+    if (t < 2 * EMB) sv[t] = vg;      // g2 | bf
+    __syncthreads();
     auto emit = [&](float* dst, float gi) {
         *dst = gi;
         const long long idx = dst - a.adam.gbase;
@@ -268,28 +285,30 @@ __global__ __launch_bounds__(256) void k_fold_grads(FoldArgs a) {
     if (part < 4) {            // dWf[i][j] = s2 * sum_k G1[i][k] * W1a[j][k]
         const int i = 16 * part + (t >> 4), j0 = (t & 15) * 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
         for (int k = 0; k < EMB; ++k) {
-            const float g = g1[i * EMB + k];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = fmaf(g, w1a[(j0 + q) * EMB + k], acc[q]);
+            const float g = sg[i * LDW + k];
+            const float4 w = *(const float4*)(sw + k * LDW + j0);
+            acc[0] = fmaf(g, w.x, acc[0]); acc[1] = fmaf(g, w.y, acc[1]); acc[2] = fmaf(g, w.z, acc[2]); acc[3] = fmaf(g, w.w, acc[3]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) emit(a.gwf[c] + i * EMB + j0 + q, s2 * acc[q]);
     } else if (part < 8) {     // dW1a[j][k] = s2 * (sum_i Wf[i][j] * G1[i][k] + bf[j] * g2[k])
         const int j = 16 * (part - 4) + (t >> 4), k0 = (t & 15) * 4;
-        const float4 gg = *(const float4*)(g2 + k0);
-        const float b = bf[j];
-        float acc[4] = {b * gg.x, b * gg.y, b * gg.z, b * gg.w};
+        const float b = sv[EMB + j];
+        float acc[4] = {b * sv[k0], b * sv[k0 + 1], b * sv[k0 + 2], b * sv[k0 + 3]};
+#pragma unroll 8
         for (int i = 0; i < EMB; ++i) {
-            const float w = wf[i * EMB + j];
-            const float4 g = *(const float4*)(g1 + i * EMB + k0);
+            const float w = sw[i * LDW + j];
+            const float4 g = *(const float4*)(sg + i * LDW + k0);
             acc[0] = fmaf(w, g.x, acc[0]); acc[1] = fmaf(w, g.y, acc[1]); acc[2] = fmaf(w, g.z, acc[2]); acc[3] = fmaf(w, g.w, acc[3]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) emit(a.gw1a[c] + j * EMB + k0 + q, s2 * acc[q]);
     } else if (t < EMB) {      // dbf[j] = s2 * sum_k W1a[j][k] * g2[k]
         float acc = 0.f;
-        for (int k = 0; k < EMB; ++k) acc = fmaf(w1a[t * EMB + k], g2[k], acc);
+#pragma unroll 8
+        for (int k = 0; k < EMB; ++k) acc = fmaf(sw[t * LDW + k], sv[k], acc);
         emit(a.gbf[c] + t, s2 * acc);
     }
 }
