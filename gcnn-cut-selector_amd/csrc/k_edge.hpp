@@ -221,8 +221,13 @@ __device__ __forceinline__ void edge_fwd_block_body(const EdgeArgs& a, const int
     const EdgeLane<4> L;
     const float4 w = *(const float4*)(a.w_edge + L.ch);
     const float esh = *a.e_shift, esc = *a.e_scale;
-    for (int r = bid; r < a.n_own; r += nblk)
+    // a block per segment (nblk = n_own): every XCD takes a contiguous range of segments, so the rows a range gathers -- the
+    // variable rows of its own samples -- stay in that XCD's L2 (round-robin placement had every XCD fetch every sample's table:
+    // 37 MB of HBM reads per pass at setcov x 32 instead of 11)
+    for (int i = bid; i < a.n_own; i += nblk) {
+        const int r = nblk == a.n_own ? xcd_remap(i, nblk) : i;
         edge_fwd_block_segment<4, COUNT>(a, s1, L, w, esh, esc, r, a.seg_ptr[r], a.seg_ptr[r + 1], red, redn);
+    }
 }
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_edge_fwd_block(EdgeArgs a) { edge_fwd_block_body<COUNT>(a, blockIdx.x, gridDim.x); }

@@ -23,14 +23,17 @@ def step_records(path, name):
         k = int(r["Dispatch_Id"])
         by_dispatch.setdefault(k, [r["Kernel_Name"].split("(")[0].replace("void ", ""), 0.0])[1] += float(r["Counter_Value"])
     steps, cur, live = [], [], False
-    for kern, val in by_dispatch.values():
+    for kern, val in by_dispatch.values():   # a step: k_embed_fwd ... up to its last launch (k_fold_grads, or k_reduce when nothing follows it)
+        if live and (kern.startswith("k_embed_fwd") or not kern.startswith("k_")):
+            steps.append(cur)
+            live = False
         if kern.startswith("k_embed_fwd"):
             cur, live = [], True
         if live:
             cur.append((kern, val))
-            if kern.startswith("k_reduce"):
-                steps.append(cur)
-                live = False
+    if live:
+        steps.append(cur)
+    steps = [s for s in steps if s[-1][0].startswith(("k_fold_grads", "k_reduce"))]
     if not steps:
         return []
     common = collections.Counter(tuple(k for k, _ in s) for s in steps).most_common(1)[0][0]
