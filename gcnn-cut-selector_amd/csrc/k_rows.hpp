@@ -222,6 +222,12 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
         for (int f = 0; f < F; ++f) dst[f] = row < a.n ? a.x[(size_t)row * F + f] : 0.f;
     };
     load_ops(xv, tile);
+    // the first-layer kernel [F][64] is requested BEFORE the staging of the matrices (whose LDS writes wait for their loads): one
+    // memory round trip for the whole prologue instead of two
+    constexpr int W1N = (F * 64 + NT - 1) / NT;
+    float w1r[W1N];
+#pragma unroll
+    for (int q = 0; q < W1N; ++q) { const int i = threadIdx.x + q * NT; w1r[q] = i < F * 64 ? a.w1[i] : 0.f; }
     if (NPROJ == 2) {
         const float* const w[3] = {a.w2, a.wp[0], a.wp[1]};
         const float* const v[4] = {a.b1, a.b2, a.bp[0], a.bp[1]};
@@ -231,7 +237,8 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
         const float* const v[3] = {a.b1, a.b2, a.bp[0]};
         stage_lds<2, 3, NT, true>((float*)smem, w, v);
     }
-    for (int i = threadIdx.x; i < F * 64; i += NT) w1s[i] = a.w1[i];
+#pragma unroll
+    for (int q = 0; q < W1N; ++q) { const int i = threadIdx.x + q * NT; if (i < F * 64) w1s[i] = w1r[q]; }
     float shift[F], scale[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) { shift[f] = a.shift[f]; scale[f] = a.scale[f]; }
