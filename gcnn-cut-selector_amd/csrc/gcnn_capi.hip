@@ -213,8 +213,12 @@ struct Acts {
     float *E1v, *Xv, *PR1, *PR2, *S2, *A2, *Z1v, *Xv2, *PR3;    // V rows
     float *E1k, *Xk, *PL3, *S3, *A3, *Z1k, *Xk2, *O1;           // K rows
 };
+struct Masks {   // ReLU patterns, 8 B per row (k_rows.hpp, mask16): of the embedding layers and of each convolution's Z1 and X'
+    mask16 *E1c, *Xc, *Z1c, *Xc2, *E1v, *Xv, *Z1v, *Xv2, *E1k, *Xk, *Z1k, *Xk2;
+};
 struct Work {
     Acts a, g;            // activations and their gradients
+    Masks m;
     float* partial;       // weight-gradient slabs
     float* dwp[3];        // per-block partials of d w_edge, one [GCNN_EDGE_DW_PARTS,64] array per convolution
     float* dwp2[3];       // ... and their pre-reduction to [GCNN_EDGE_DW_PARTS / DW_CHUNK, 64] (k_wgrad's third block type)
@@ -243,6 +247,14 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
         for (auto p : pc) *p = take(C * EMB);
         for (auto p : pv) *p = take(V * EMB);
         for (auto p : pk) *p = take(K * EMB);
+    }
+    {
+        mask16** mc[] = {&w->m.E1c, &w->m.Xc, &w->m.Z1c, &w->m.Xc2};
+        mask16** mv[] = {&w->m.E1v, &w->m.Xv, &w->m.Z1v, &w->m.Xv2};
+        mask16** mk[] = {&w->m.E1k, &w->m.Xk, &w->m.Z1k, &w->m.Xk2};
+        for (auto q : mc) *q = (mask16*)take(2 * C);      // 8 B = two floats per row
+        for (auto q : mv) *q = (mask16*)take(2 * V);
+        for (auto q : mk) *q = (mask16*)take(2 * K);
     }
     w->partial = take(wg_slabs(d) * WG_SLAB);
     const size_t nrecv[3] = {C, V, K};
@@ -660,6 +672,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *DWP, *DWP2;
     float* N;
     float *FZ, *GFZ;       // folded weights M | u and their raw gradients G1 | g2
+    mask16 *mZ1, *mOUT;    // ReLU patterns of Z1 and OUT
 };
 
 static EdgeArgs conv_edge_args(const float* p, const ConvIO& c, bool by_left) {
@@ -688,7 +701,7 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
     a.mfuse = c.FZ; a.ufuse = c.FZ + EMB * EMB;
     a.s2 = p + poff(c.pbase + C_S2); a.xrecv = c.recv_left ? c.xl : c.xv;
     a.w1a = p + poff(c.pbase + C_W1); a.w1b = p + poff(c.pbase + C_W1) + EMB * EMB; a.b1 = p + poff(c.pbase + C_B1);
-    a.z1 = save ? c.Z1 : nullptr;
+    a.z1 = save ? c.Z1 : nullptr; a.m_z1 = save ? c.mZ1 : nullptr; a.m_out = save ? c.mOUT : nullptr;
     a.w2 = p + poff(c.pbase + C_W2); a.b2 = p + poff(c.pbase + C_B2); a.out = c.OUT;
     a.wt = wt; a.bt = bt; a.t_out = t_out;
     if (tail != CF_PROJ) { a.ws = p + poff(P_OUT + 2); a.bs = p + poff(P_OUT + 3); a.scores = scores; }
@@ -702,11 +715,11 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0], w.fuse[0], w.gfuse[0]};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0], w.fuse[0], w.gfuse[0], w.m.Z1c, w.m.Xc2};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1], w.fuse[1], w.gfuse[1]};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1], w.fuse[1], w.gfuse[1], w.m.Z1v, w.m.Xv2};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2], w.fuse[2], w.gfuse[2]};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2], w.fuse[2], w.gfuse[2], w.m.Z1k, w.m.Xk2};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -736,16 +749,16 @@ static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_fe
     // independent programs, one grouped launch
     {
         EmbGroupArgs m; memset(&m, 0, sizeof(m));
-        auto emb = [&](EmbArgs& e, const float* x, int pb, float* e1, float* xo, int n) {
+        auto emb = [&](EmbArgs& e, const float* x, int pb, float* e1, float* xo, int n, mask16* me1, mask16* mx) {
             e.x = x; e.shift = p + poff(pb + E_SHIFT); e.scale = p + poff(pb + E_SCALE); e.w1 = p + poff(pb + E_W1);
             e.b1 = p + poff(pb + E_B1); e.e1 = save ? e1 : nullptr; e.w2 = p + poff(pb + E_W2); e.b2 = p + poff(pb + E_B2);
-            e.xo = xo; e.n = n;
+            e.xo = xo; e.n = n; e.m_e1 = save ? me1 : nullptr; e.m_x = save ? mx : nullptr;
         };
-        emb(m.v, var_feats, P_VAR, A.E1v, A.Xv, d->n_vars);    // variables: E1 -> Xv -> PR1, PR2 (model.py:294-295)
+        emb(m.v, var_feats, P_VAR, A.E1v, A.Xv, d->n_vars, w.m.E1v, w.m.Xv);    // variables: E1 -> Xv -> PR1, PR2 (model.py:294-295)
         m.v.wp[0] = p + poff(P_CONV0 + C_WR); m.v.po[0] = A.PR1; m.v.wp[1] = p + poff(P_CONV1 + C_WR); m.v.po[1] = A.PR2;
-        emb(m.c, cons_feats, P_CONS, A.E1c, A.Xc, d->n_cons);  // constraints: E1 -> Xc -> PL1
+        emb(m.c, cons_feats, P_CONS, A.E1c, A.Xc, d->n_cons, w.m.E1c, w.m.Xc);  // constraints: E1 -> Xc -> PL1
         m.c.wp[0] = p + poff(P_CONV0 + C_WL); m.c.bp[0] = p + poff(P_CONV0 + C_BL); m.c.po[0] = A.PL1;
-        emb(m.k, cut_feats, P_CUT, A.E1k, A.Xk, d->n_cuts);    // cuts: E1 -> Xk -> PL3
+        emb(m.k, cut_feats, P_CUT, A.E1k, A.Xk, d->n_cuts, w.m.E1k, w.m.Xk);    // cuts: E1 -> Xk -> PL3
         m.k.wp[0] = p + poff(P_CONV2 + C_WL); m.k.bp[0] = p + poff(P_CONV2 + C_BL); m.k.po[0] = A.PL3;
         const int convs[3] = {P_CONV0, P_CONV1, P_CONV2};     // the folded weights of the three convolutions ride in this launch
         for (int k = 0; k < 3; ++k) {
@@ -871,7 +884,7 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
 
 
 // ---- backward ---------------------------------------------------------------------------------------------------
-struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; const float *mask, *shift, *scale; int f; };
+struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; const mask16* mask; const float *shift, *scale; int f; };
 struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
@@ -884,8 +897,9 @@ static void add_wg(JobList& jl, const float* x, const float* sx, const float* dm
     if (n <= 0) return;  // empty input: gradients are exactly zero
     jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2, nullptr, nullptr, nullptr, 0};
 }
-// first layer of an embedding: x = raw features [n][f], dmat = dE1 (unmasked), e1 = the layer's output (k_wgrad.hpp, EXTRA == 2)
-static void add_wg_emb1(JobList& jl, const float* x, const float* shift, const float* scale, const float* dmat, const float* e1,
+// first layer of an embedding: x = raw features [n][f], dmat = dE1 (unmasked), e1 = the ReLU pattern of the layer's output
+// (k_wgrad.hpp, EXTRA == 2)
+static void add_wg_emb1(JobList& jl, const float* x, const float* shift, const float* scale, const float* dmat, const mask16* e1,
                         int n, int f, float* gw, float* gb) {
     if (n <= 0) return;
     jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f};
@@ -955,8 +969,8 @@ static void add_rd(JobList& jl, const float* src, float* dst, int nparts, int st
 static ConvBArgs conv_bwd_args(const float* p, const ConvIO& c, const float* in, const float* w0) {
     ConvBArgs a; memset(&a, 0, sizeof(a));
     a.n = c.recv_left ? c.nl : c.nv;
-    a.in = in; a.w0 = w0; a.x_out = c.OUT; a.g_out = c.gOUT;
-    a.w2 = p + poff(c.pbase + C_W2); a.z1 = c.Z1; a.g_z1 = c.gZ1;
+    a.in = in; a.w0 = w0; a.m_out = c.mOUT; a.g_out = c.gOUT;
+    a.w2 = p + poff(c.pbase + C_W2); a.m_z1 = c.mZ1; a.g_z1 = c.gZ1;
     a.w1b = p + poff(c.pbase + C_W1) + EMB * EMB; a.g_xrecv = c.recv_left ? c.gXL : c.gXV;
     a.mfuse = c.FZ; a.g_s = c.gS;
     a.s1 = p + poff(c.pbase + C_S1); a.nrows = c.N; a.g_precv = c.recv_left ? c.gPL : c.gPR;
@@ -1039,10 +1053,10 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
     if (d->n_cuts <= 0) return adam_after();  // no cut => every gradient is 0
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
-    struct { const float* x; const float* e1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
-        {cons_feats, A.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
-        {var_feats, A.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
-        {cut_feats, A.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
+    struct { const float* x; const float* e1; const mask16* me1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
+        {cons_feats, A.E1c, w.m.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
+        {var_feats, A.E1v, w.m.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
+        {cut_feats, A.E1k, w.m.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
     // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
     int head_parts = w.score_nblk;
     if (fused_head) {
@@ -1058,9 +1072,9 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     add_rd(jl, w.score_partial, grads + poff(P_OUT + 2), head_parts, HEAD_SLAB, EMB);
     add_rd(jl, w.score_partial + EMB, grads + poff(P_OUT + 3), head_parts, HEAD_SLAB, 1);
     add_wg(jl, A.Xk2, nullptr, G.O1, nullptr, d->n_cuts, grads + poff(P_OUT), grads + poff(P_OUT + 1), nullptr, w.partial);
-    auto tail = [&](TailBArgs& t, const float* in_a, const float* wa, const float* in_b, const float* wb, float* gx, const float* x,
+    auto tail = [&](TailBArgs& t, const float* in_a, const float* wa, const float* in_b, const float* wb, float* gx, const mask16* mx,
                     int pb, float* ge1, int n) {
-        t.in_a = in_a; t.wa = wa; t.in_b = in_b; t.wb = wb; t.add = gx; t.x = x; t.g_x = gx; t.w2 = p + poff(pb + E_W2);
+        t.in_a = in_a; t.wa = wa; t.in_b = in_b; t.wb = wb; t.add = gx; t.m_x = mx; t.g_x = gx; t.w2 = p + poff(pb + E_W2);
         t.g_e1 = ge1; t.n = n;
     };
     if (!fused_head) {   // cut rows: readout -> conv v->k receiver gradients (fused head: gcnn_forward_loss's last launch did it)
@@ -1073,7 +1087,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
         // dXk = dXk(W1b part) + dPL3 Wl3^T, masked by Xk; dE1k
         ConvBGroupArgs m; memset(&m, 0, sizeof(m));
         m.cb = conv_bwd_args(p, cv[1], G.PR3, p + poff(P_CONV2 + C_WR));
-        tail(m.tail, G.PL3, p + poff(P_CONV2 + C_WL), nullptr, nullptr, G.Xk, A.Xk, P_CUT, G.E1k, d->n_cuts);
+        tail(m.tail, G.PL3, p + poff(P_CONV2 + C_WL), nullptr, nullptr, G.Xk, w.m.Xk, P_CUT, G.E1k, d->n_cuts);
         if ((rc = launch_conv_bwd(m, st))) return rc;
     }
     if ((rc = conv_backward_edges(p, grads, cv[1], w, jl, st))) return rc;
@@ -1086,8 +1100,8 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     {   // variable rows: dXv = dXv(W1b part) + dPR2 Wr2^T + dPR1 Wr1^T, masked by Xv; dE1v; in the same launch the
         // constraint rows' tail: dXc = dXc(W1b part) + dPL1 Wl1^T, masked by Xc; dE1c
         TailGroupArgs m; memset(&m, 0, sizeof(m));
-        tail(m.a, G.PR2, p + poff(P_CONV1 + C_WR), G.PR1, p + poff(P_CONV0 + C_WR), G.Xv, A.Xv, P_VAR, G.E1v, d->n_vars);
-        tail(m.b, G.PL1, p + poff(P_CONV0 + C_WL), nullptr, nullptr, G.Xc, A.Xc, P_CONS, G.E1c, d->n_cons);
+        tail(m.a, G.PR2, p + poff(P_CONV1 + C_WR), G.PR1, p + poff(P_CONV0 + C_WR), G.Xv, w.m.Xv, P_VAR, G.E1v, d->n_vars);
+        tail(m.b, G.PL1, p + poff(P_CONV0 + C_WL), nullptr, nullptr, G.Xc, w.m.Xc, P_CONS, G.E1c, d->n_cons);
         if ((rc = launch_tail_bwd(m, st))) return rc;
     }
     // Weight gradients: every operand pair now exists, so ALL of them go out as two grouped launches -- the 22 [64,64]
@@ -1095,7 +1109,7 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     // the slabs.  (Running them beside the critical path on side streams was slower: a cross-stream event edge costs
     // 7-14 us here.)
     for (int i = 0; i < 3; ++i)   // kernel [f,64] and bias [64] are separate (4-float aligned) tensors in the layout
-        add_wg_emb1(jl, em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].e1, em[i].n, em[i].f,
+        add_wg_emb1(jl, em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].me1, em[i].n, em[i].f,
                     grads + poff(em[i].pb + E_W1), grads + poff(em[i].pb + E_B1));
     for (int i = 0; i < 3; ++i)
         add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);

@@ -141,6 +141,32 @@ __device__ __forceinline__ void rt_mask(RTile& o, const RTile& act) {   // o *= 
 #pragma unroll
         for (int i = 0; i < 4; ++i) o.v[m][i] = act.v[m][i] > 0.f ? o.v[m][i] : 0.f;
 }
+// ReLU patterns as bits.  A ReLU output that the backward pass needs only as a mask (X', Z1 of a convolution in its gradient
+// program, a raw embedding X in its tail, E1 in the first layer's weight gradient) is not re-read as a [N,64] fp32 matrix
+// (256 B per row) but as 64 bits per row: lane (j, g) of a tile keeps the 16 bits of ITS 16 values -- bit 4m+i <-> feature
+// 16m+4g+i -- as one 16-bit word at mask[row][g] (8 B per row).  Writer and reader are the same lane of the same tile layout, so
+// no bit crosses a lane; a 16-row tile's masks are 128 contiguous bytes.
+typedef unsigned short mask16;
+__device__ __forceinline__ unsigned rt_mask_bits(const RTile& t) {
+    unsigned b = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b |= (t.v[m][i] > 0.f ? 1u : 0u) << (4 * m + i);
+    return b;
+}
+__device__ __forceinline__ void rt_mask_store(const RTile& t, mask16* dst, int row, bool ok, int g) {
+    if (ok && dst) dst[(size_t)row * 4 + g] = (mask16)rt_mask_bits(t);
+}
+__device__ __forceinline__ unsigned rt_mask_load(const mask16* src, int row, bool ok, int g) {
+    return ok ? (unsigned)src[(size_t)row * 4 + g] : 0u;
+}
+__device__ __forceinline__ void rt_mask_apply(RTile& o, unsigned bits) {   // o *= pattern: gradient of a ReLU whose output had this pattern
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[m][i] = (bits >> (4 * m + i)) & 1u ? o.v[m][i] : 0.f;
+}
 __device__ __forceinline__ void rt_clear_unless(RTile& o, bool ok) {    // rows past the end of the matrix stay exactly zero
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -202,8 +228,8 @@ __device__ __forceinline__ void stage_lds(float* smem, const float* const (&w)[N
 //   P_k = X Wp_k (+ bp_k)                        k < NPROJ               -> po[k]
 // ---------------------------------------------------------------------------------------------------------------
 struct EmbArgs {
-    const float *x, *shift, *scale, *w1, *b1; float* e1;
-    const float *w2, *b2; float* xo;
+    const float *x, *shift, *scale, *w1, *b1; float* e1; mask16* m_e1;    // m_e1, m_x: ReLU patterns for the backward pass (optional)
+    const float *w2, *b2; float* xo; mask16* m_x;
     const float* wp[2]; const float* bp[2]; float* po[2];
     int n;
 };
@@ -263,10 +289,12 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
         rt_bias<true>(o, vecs, g);
         rt_clear_unless(o, ok);
         rt_store(o, a.e1, row, ok, g);
+        rt_mask_store(o, a.m_e1, row, ok, g);
         rt_mm<false>(t, o, 1.f, smem, lane);
         rt_bias<true>(t, vecs + 64, g);
         rt_clear_unless(t, ok);
         rt_store(t, a.xo, row, ok, g);
+        rt_mask_store(t, a.m_x, row, ok, g);
 #pragma unroll
         for (int k = 0; k < NPROJ; ++k) {
             rt_mm<false>(o, t, 1.f, smem + (1 + k) * 64 * LDW, lane);
@@ -349,8 +377,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
 struct ConvFArgs {
     const float* s; const int* seg_ptr; const float *wf, *bf; float* a_out;     // wf, bf, a_out, s2, w1a: the KEEP_A form only
     const float *mfuse, *ufuse;                                                    // M = s2*Wf*W1a [64,64], u = s2*bf*W1a [64] (k_fuse)
-    const float *s2, *xrecv, *w1a, *w1b, *b1; float* z1;
-    const float *w2, *b2; float* out;
+    const float *s2, *xrecv, *w1a, *w1b, *b1; float* z1; mask16* m_z1;     // m_z1, m_out: ReLU patterns for the gradient program (optional)
+    const float *w2, *b2; float* out; mask16* m_out;
     const float *wt, *bt; float* t_out;      // readout: wt/bt = readout Dense(64,relu), t_out = O1
     const float *ws, *bs; float* scores;      // readout only
     const float* targets; float loss_scale; float* g_o1; float* head_partial;   // CF_LOSS only; partial: [tiles][HEAD_SLAB]
@@ -459,10 +487,12 @@ __device__ __forceinline__ void convf_program(const ConvFArgs& a, float* smem, i
         rt_bias<true>(t1, vecs + 64, g);
         rt_clear_unless(t1, ok);
         rt_store(t1, a.z1, row, ok, g);
+        rt_mask_store(t1, a.m_z1, row, ok, g);
         rt_mm<false>(t0, t1, 1.f, smem + iW2 * 64 * LDW, lane);
         rt_bias<true>(t0, vecs + 2 * 64, g);
         rt_clear_unless(t0, ok);
         rt_store(t0, a.out, row, ok, g);
+        rt_mask_store(t0, a.m_out, row, ok, g);
         rt_mm<false>(t1, t0, 1.f, smem + iWT * 64 * LDW, lane);
         if (TAIL == CF_PROJ) {
             rt_bias<false>(t1, vecs + 3 * 64, g);
@@ -498,8 +528,8 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_fwd(ConvFArgs a) {
 //   dP_recv = s1 * dS * N   (receiver-ordered half of the edge gradient, see k_edge_fwd)   -> g_precv
 // ---------------------------------------------------------------------------------------------------------------
 struct ConvBArgs {
-    const float *in, *w0, *x_out; float* g_out;
-    const float *w2, *z1; float* g_z1;
+    const float *in, *w0; const mask16* m_out; float* g_out;     // m_out, m_z1: the ReLU patterns of X' and Z1 (Program 2)
+    const float* w2; const mask16* m_z1; float* g_z1;
     const float* w1b; float* g_xrecv;
     const float* mfuse; float* g_s;
     const float *s1, *nrows; float* g_precv;
@@ -511,13 +541,13 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
-    struct Ops { RTile in, m0, m1, nr; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
+    struct Ops { RTile in, nr; unsigned m0, m1; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
     auto load_ops = [&](Ops& d, int t) {
         const int row = t * 16 + j;
         const bool ok = row < a.n;
         rt_load(d.in, a.in, row, ok, g);
-        rt_load(d.m0, a.x_out, row, ok, g);
-        rt_load(d.m1, a.z1, row, ok, g);
+        d.m0 = rt_mask_load(a.m_out, row, ok, g);
+        d.m1 = rt_mask_load(a.m_z1, row, ok, g);
         rt_load(d.nr, a.nrows, row, ok, g);
     };
     load_ops(cur, tile);
@@ -530,15 +560,15 @@ __device__ __forceinline__ void convb_program(const ConvBArgs& a, float* smem, i
     __syncthreads();
     for (; tile < ntile; tile += nblk * NWAVES) {
         load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
-        const RTile &in = cur.in, &m0 = cur.m0, &m1 = cur.m1, &nr = cur.nr;
+        const RTile &in = cur.in, &nr = cur.nr;
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;
         rt_mm<true>(t0, in, 1.f, smem, lane);
-        rt_mask(t0, m0);
+        rt_mask_apply(t0, cur.m0);
         rt_store(t0, a.g_out, row, ok, g);
         rt_mm<true>(t1, t0, 1.f, smem + 64 * LDW, lane);
-        rt_mask(t1, m1);
+        rt_mask_apply(t1, cur.m1);
         rt_store(t1, a.g_z1, row, ok, g);
         rt_mm<true>(t0, t1, 1.f, smem + 2 * 64 * LDW, lane);
         rt_store(t0, a.g_xrecv, row, ok, g);
@@ -653,7 +683,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_conv_turn(ConvFArgs f, ConvBArg
 //   dE1 = dX W2^T                      (masked later, inside the first layer's weight-gradient kernel)   -> g_e1
 // ---------------------------------------------------------------------------------------------------------------
 struct TailBArgs {
-    const float *in_a, *wa, *in_b, *wb, *add, *x; float* g_x;
+    const float *in_a, *wa, *in_b, *wb, *add; const mask16* m_x; float* g_x;    // m_x: the ReLU pattern of the raw embedding X
     const float* w2; float* g_e1;
     int n;
 };
@@ -663,14 +693,14 @@ __device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, i
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int ntile = (a.n + 15) >> 4;
     int tile = bid + nblk * wv;   // tiles are dealt round-robin over the blocks, then over a block's waves
-    struct Ops { RTile ia, ib, ad, mk; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
+    struct Ops { RTile ia, ib, ad; unsigned mk; } cur, nxt;   // current tile / the wave's next tile (requested one tile ahead)
     auto load_ops = [&](Ops& d, int t) {
         const int row = t * 16 + j;
         const bool ok = row < a.n;
         rt_load(d.ia, a.in_a, row, ok, g);
         if (HAS_INB) rt_load(d.ib, a.in_b, row, ok, g);
         rt_load(d.ad, a.add, row, ok, g);
-        rt_load(d.mk, a.x, row, ok, g);
+        d.mk = rt_mask_load(a.m_x, row, ok, g);
     };
     load_ops(cur, tile);
     const float* const v[1] = {nullptr};
@@ -679,7 +709,7 @@ __device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, i
     __syncthreads();
     for (; tile < ntile; tile += nblk * NWAVES) {
         load_ops(nxt, tile + nblk * NWAVES);   // past the last tile: no loads
-        const RTile &ia = cur.ia, &ib = cur.ib, &ad = cur.ad, &mk = cur.mk;
+        const RTile &ia = cur.ia, &ib = cur.ib, &ad = cur.ad;
         const int row = tile * 16 + j;
         const bool ok = row < a.n;
         RTile t0, t1;
@@ -689,7 +719,7 @@ __device__ __forceinline__ void tailb_program(const TailBArgs& a, float* smem, i
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) t0.v[m][i] += ad.v[m][i];
-        rt_mask(t0, mk);
+        rt_mask_apply(t0, cur.mk);
         rt_store(t0, a.g_x, row, ok, g);
         rt_mm<true>(t1, t0, 1.f, smem + 64 * LDW, lane);
         rt_store(t1, a.g_e1, row, ok, g);

@@ -134,11 +134,13 @@ __device__ __forceinline__ void emb_split(const EmbArgs& a, float* smem, int bid
         rq_clear_unless(q, ok);
         rq_store(q, a.e1, row, ok, L);
         rq_exchange(full, q, L);
+        if (L.wv == 0) rt_mask_store(full, a.m_e1, row, ok, L.g);   // every wave holds the whole tile now: one of them writes its pattern
         rq_mm<GEMM_FWD>(q, full, 1.f, smem, L);
         rq_bias<true>(q, vecs + 64, L);
         rq_clear_unless(q, ok);
         rq_store(q, a.xo, row, ok, L);
         rq_exchange(t, q, L);
+        if (L.wv == 0) rt_mask_store(t, a.m_x, row, ok, L.g);
 #pragma unroll
         for (int k = 0; k < NPROJ; ++k) {
             rq_mm<GEMM_FWD>(q, t, 1.f, smem + (1 + k) * 64 * LDW, L);
@@ -196,11 +198,13 @@ __device__ __forceinline__ void convf_split(const ConvFArgs& a, float* smem, int
         rq_clear_unless(q, ok);
         rq_store(q, a.z1, row, ok, L);
         rq_exchange(z, q, L);
+        if (L.wv == 0) rt_mask_store(z, a.m_z1, row, ok, L.g);
         rq_mm<GEMM_FWD>(q, z, 1.f, smem + iW2 * 64 * LDW, L);
         rq_bias<true>(q, vecs + 2 * 64, L);
         rq_clear_unless(q, ok);
         rq_store(q, a.out, row, ok, L);
         rq_exchange(full, q, L);
+        if (L.wv == 0) rt_mask_store(full, a.m_out, row, ok, L.g);
         rq_mm<GEMM_FWD>(q, full, 1.f, smem + iWT * 64 * LDW, L);
         if (TAIL == CF_PROJ) {
             rq_bias<false>(q, vecs + 3 * 64, L);

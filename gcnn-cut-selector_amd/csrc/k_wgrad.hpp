@@ -24,14 +24,15 @@
 #define WG_RING 2    // batches in the load ring (WG_RING - 1 in flight behind the one being multiplied; 3 and 4 measured: no gain)
 #endif
 // f > 0: the job is the FIRST layer of an embedding, relu(((x+shift)*scale) @ W[f,64] + b) (model.py:174-177 and twins):
-//        x = the raw features [n][f], d = dE1 still unmasked, mask = E1 (the ReLU output); G is [f,64] (rows >= f: zeros)
-struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const float *mask, *shift, *scale;
+//        x = the raw features [n][f], d = dE1 still unmasked, mask = the ReLU pattern of E1 (k_rows.hpp, mask16: 8 B per row);
+//        G is [f,64] (rows >= f: zeros)
+struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const unsigned short* mask; const float *shift, *scale;
                int n; int blk0; int slab0; int f;
                int nb, rows; };   // blocks of the job; rows per wave (a multiple of 16: the job's rows spread evenly over nb * 4 waves)
 struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
-struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS], k[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };
+struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };   // p0 / p1: segment offsets (EXTRA 1) or the raw mask word (EXTRA 2)
 
 // EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f),
 //        2 = first embedding layer: X^T has only f <= 14 (padded to 16) rows, so lane (m, g) loads ONE raw feature x[row][m]
@@ -46,7 +47,9 @@ __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, i
         const int r = min(row0 + 4 * s + g, rend - 1);   // callers guarantee rend > 0
         if (EXTRA == 2) {
             t.x[s] = make_float4(jb.x[(size_t)r * jb.f + min(col >> 2, jb.f - 1)], 0.f, 0.f, 0.f);   // lanes m >= f: scale 0 below
-            t.k[s] = *(const float4*)(jb.mask + (size_t)r * EMB + col);
+            // columns 4m..4m+3 of row r (m = col/4 = 4a + b) are nibble a of the word at mask[r][b] (bit 4a+i <-> feature 16a+4b+i);
+            // kept raw here (decoding would wait for the load), decoded at use
+            t.p0[s] = jb.mask[(size_t)r * 4 + ((col >> 2) & 3)];
         } else t.x[s] = *(const float4*)(jb.x + (size_t)r * EMB + col);
         t.d[s] = *(const float4*)(jb.d + (size_t)r * EMB + col);
         if (EXTRA == 1) { t.p0[s] = jb.seg_ptr[r]; t.p1[s] = jb.seg_ptr[r + 1]; }   // raw: converting here would wait
@@ -72,9 +75,9 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
             for (int v = 0; v < 4; ++v) { xa[v] = live ? xa[v] : 0.f; db[v] = live ? db[v] : 0.f; }
             if (EXTRA == 2) {
                 xa[0] = (xa[0] + shift) * scale;
-                const float mk[4] = {cur.k[s].x, cur.k[s].y, cur.k[s].z, cur.k[s].w};
+                const unsigned nib = (unsigned)cur.p0[s] >> ((col >> 2) & ~3);
 #pragma unroll
-                for (int vb = 0; vb < 4; ++vb) db[vb] = mk[vb] > 0.f ? db[vb] : 0.f;
+                for (int vb = 0; vb < 4; ++vb) db[vb] = (nib >> vb) & 1u ? db[vb] : 0.f;
             }
 #pragma unroll
             for (int va = 0; va < (EXTRA == 2 ? 1 : 4); ++va)

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 3; ++i) {
                 const int j = a.njobs++;
                 const int nb = cdiv(ns[i], c.rows * WG_WAVES);
-                a.job[j] = WgJob{feat, nullptr, d + (size_t)i * NMAX * 64, nullptr, x + (size_t)i * NMAX * 64, sx, sx, ns[i], blk, slab, fs[i],
+                a.job[j] = WgJob{feat, nullptr, d + (size_t)i * NMAX * 64, nullptr, (const unsigned short*)(x + (size_t)i * NMAX * 64), sx, sx, ns[i], blk, slab, fs[i],   // mask: 8 B of pattern bits per row
                                  nb, (cdiv(ns[i], nb * WG_WAVES) + 15) & ~15};
                 blk += c.pad8 ? (nb + 7) & ~7 : nb; slab += nb; nemb += nb;
             }
