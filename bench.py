@@ -232,30 +232,31 @@ def roofline_step(model, batch, targets, dev, steps=20):
     # k_wgrad reads several tensors in more than one job (dZ1 feeds the folded layers' product and the lower half of W1, a raw
     # embedding X up to three products): `hbm_bytes` counts each once (11 / 12 / 11 distinct tensors per constraint / variable /
     # cut row: 5 X operands and 6 / 7 / 6 D operands) plus the raw features, the segment offsets and the partial slabs it
-    # writes; `hbm_bytes_per_job` charges every job its own operands (14 / 16 / 14 per row: 6 / 7 / 6 products + the first
-    # embedding layer) -- what the launch would move if no second read hit L2.  PMC traffic (FETCH_SIZE + WRITE_SIZE) lies between.
-    wg_min = row * (11 * C + 12 * V + 11 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 4.0 * (C + V + K)
-    wg_job = row * (14 * C + 16 * V + 14 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 4.0 * (C + V + K)
+    # writes; `hbm_bytes_per_job` charges every job its own operands (13 / 15 / 13 per row: 6 / 7 / 6 products + the first
+    # embedding layer's dE1; its ReLU pattern is 8 B per row) -- what the launch would move if no second read hit L2.  PMC
+    # traffic (FETCH_SIZE + WRITE_SIZE) lies between.
+    wg_min = row * (11 * C + 12 * V + 11 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 12.0 * (C + V + K)
+    wg_job = row * (13 * C + 15 * V + 13 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 12.0 * (C + V + K)
     wg_flops = mm * (6 * C + 7 * V + 6 * K) + 2.0 * 16 * 64 * (C + V + K)
     edge_f = lambda e, own, oth: 8.0 * e + row * (own + oth) + 2 * row * own    # tables in, S + N out, (index, coef) per edge
     edge_b = lambda e, own, oth: 8.0 * e + row * (own + 2 * oth) + row * own    # P_send, P_recv + dS in, dP_send out
     model_of = {
-        ("k_embed_fwd", 0): ("3 embeddings + 4 projections", V * (56 + 4 * row) + C * (16 + 3 * row) + K * (24 + 3 * row),
+        ("k_embed_fwd", 0): ("3 embeddings + 4 projections", V * (56 + 4 * row + 16) + C * (16 + 3 * row + 16) + K * (24 + 3 * row + 16),
                              V * (2 * 14 * 64 + 3 * mm) + C * (2 * 4 * 64 + 2 * mm) + K * (2 * 6 * 64 + 2 * mm), 0),
         ("k_edge_fwd<count>", 0): ("conv v->c edge pass", edge_f(E1, C, V), 14.0 * 64 * E1, row * E1),
-        ("k_conv_fwd<proj>", 0): ("conv v->c receiver update (C rows)", C * 5 * row, C * 4 * mm, 0),
+        ("k_conv_fwd<proj>", 0): ("conv v->c receiver update (C rows)", C * (5 * row + 16), C * 4 * mm, 0),
         ("k_edge_fwd<count>", 1): ("conv c->v edge pass", edge_f(E1, V, C), 14.0 * 64 * E1, row * E1),
-        ("k_conv_fwd<proj>", 1): ("conv c->v receiver update (V rows)", V * 5 * row, V * 4 * mm, 0),
+        ("k_conv_fwd<proj>", 1): ("conv c->v receiver update (V rows)", V * (5 * row + 16), V * 4 * mm, 0),
         ("k_edge_fwd<count>", 2): ("conv v->k edge pass", edge_f(E2, K, V), 14.0 * 64 * E2, row * E2),
         ("k_edge_fwd_block<count>", 0): ("conv v->k edge pass (a block per cut row)", edge_f(E2, K, V), 14.0 * 64 * E2, row * E2),
         ("k_conv_turn (readout + loss head + cut-row gradients)", 0):
             ("conv v->k receiver update + readout + MSE head + receiver gradients (K rows, one launch)", K * 11 * row, K * 8 * mm, 0),
         ("k_edge_bwd_send", 0): ("conv v->k sender gradients", edge_b(E2, V, K), 22.0 * 64 * E2, 2 * row * E2),
-        ("k_conv_bwd", 0): ("conv c->v receiver gradients (V rows) + cut tail", V * 9 * row + K * 5 * row, V * 4 * mm + K * 2 * mm, 0),
+        ("k_conv_bwd", 0): ("conv c->v receiver gradients (V rows) + cut tail", V * (7 * row + 16) + K * (4 * row + 8), V * 4 * mm + K * 2 * mm, 0),
         ("k_edge_bwd_send", 1): ("conv c->v sender gradients", edge_b(E1, C, V), 22.0 * 64 * E1, 2 * row * E1),
-        ("k_conv_bwd", 1): ("conv v->c receiver gradients (C rows)", C * 9 * row, C * 4 * mm, 0),
+        ("k_conv_bwd", 1): ("conv v->c receiver gradients (C rows)", C * (7 * row + 16), C * 4 * mm, 0),
         ("k_edge_bwd_send", 2): ("conv v->c sender gradients", edge_b(E1, V, C), 22.0 * 64 * E1, 2 * row * E1),
-        ("k_tail_bwd", 0): ("embedding tails (V and C rows)", V * 6 * row + C * 5 * row, V * 3 * mm + C * 2 * mm, 0),
+        ("k_tail_bwd", 0): ("embedding tails (V and C rows)", V * (5 * row + 8) + C * (4 * row + 8), V * 3 * mm + C * 2 * mm, 0),
         ("k_wgrad", 0): ("19 weight-gradient products + 3 first layers", wg_min, wg_flops, 0),
     }
     pmc = step_traffic(d)

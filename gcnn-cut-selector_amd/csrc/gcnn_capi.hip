@@ -115,7 +115,7 @@ static LinArgs lin_bwd(const float* dy, const float* ymask, const float* wa, flo
 // whole wave per segment, mean degree 25 with two to four segments per wave.
 static inline int edge_slots(int n_own, int n_edges) {
     const double avg = (double)n_edges / (double)std::max(n_own, 1);
-    return avg >= 40.0 ? 4 : (avg >= 12.0 ? 2 : 1);
+    return avg >= GCNN_KNOB("GCNN_SLOTS4_DEG", 40) ? 4 : (avg >= GCNN_KNOB("GCNN_SLOTS2_DEG", 12) ? 2 : 1);
 }
 // Segments longer than edge_long_threshold(slots) are left to a second launch that gives each a whole wave (k_edge.hpp).
 // max_deg = longest segment of the list if the caller knows it (gcnn_graph.*_max_deg), 0 = unknown: then the finder always runs.
