@@ -244,9 +244,11 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
         float** pc[] = {&t->E1c, &t->Xc, &t->PL1, &t->S1, &t->A1, &t->Z1c, &t->Xc2, &t->PL2};
         float** pv[] = {&t->E1v, &t->Xv, &t->PR1, &t->PR2, &t->S2, &t->A2, &t->Z1v, &t->Xv2, &t->PR3};
         float** pk[] = {&t->E1k, &t->Xk, &t->PL3, &t->S3, &t->A3, &t->Z1k, &t->Xk2, &t->O1};
-        for (auto p : pc) *p = take(C * EMB);
-        for (auto p : pv) *p = take(V * EMB);
-        for (auto p : pk) *p = take(K * EMB);
+        // (no gradient of A exists since the layers around it are folded, k_rows.hpp Program 2; A itself stays: PreNorm fitting
+        // materialises it)
+        for (auto p : pc) *p = (pass && p == &t->A1) ? nullptr : take(C * EMB);
+        for (auto p : pv) *p = (pass && p == &t->A2) ? nullptr : take(V * EMB);
+        for (auto p : pk) *p = (pass && p == &t->A3) ? nullptr : take(K * EMB);
     }
     {
         mask16** mc[] = {&w->m.E1c, &w->m.Xc, &w->m.Z1c, &w->m.Xc2};

@@ -190,6 +190,25 @@ def test_backward_isolated_and_unsorted(dev):
     _grad_check(m, params, state, rng.uniform(0, 0.1, K))
 
 
+def test_two_layer_form_for_prenorm_fitting_agrees_with_the_folded_form(dev):
+    """`gcnn_forward(save_for_backward=2)` runs feature_module_final and output_module's first layer as two products and stores the
+    tensor between them (PreNorm fitting needs its statistics, model.py:503, 570); the default folds them into one matrix.
+    Same function: scores agree to rounding, and A equals S Wf + deg bf of the oracle."""
+    import ctypes as C
+    from gcnn_cut_selector_amd import _lib
+    m, params = _model(13, dev)
+    state, _, _ = synthetic.make_batch("combauc", 3)
+    batch = m.prepare(state)
+    flat = m.flat_parameters.detach()
+    ws = m._take_workspace(batch)
+    folded = m._forward_into(flat, batch, ws, save=1).cpu().numpy()
+    two_layer = m._forward_into(flat, batch, ws, save=2).cpu().numpy()
+    np.testing.assert_allclose(two_layer, folded, rtol=2e-5, atol=2e-6)
+    want = O.scores({k: v.astype(np.float64) for k, v in params.items()}, state, torch.float64)
+    np.testing.assert_allclose(two_layer, want, rtol=1e-4, atol=1e-4)
+    m._give_workspace(ws)
+
+
 def test_save_restore_roundtrip(dev, tmp_path):
     from gcnn_cut_selector_amd.model import GCNN
     m, _ = _model(9, dev)
