@@ -230,18 +230,19 @@ def roofline_step(model, batch, targets, dev, steps=20):
     # (kernel, occurrence) -> (what, HBM bytes, FLOPs, L2-gathered bytes).  HBM bytes = the MINIMUM a launch must move: every
     # DISTINCT [N,64] fp32 tensor it reads or writes counted once (256 B per row), edge lists 8 B per edge, raw features.
     # k_wgrad reads several tensors in more than one job (dZ1 feeds the folded layers' product and the lower half of W1, a raw
-    # embedding X up to three products): `hbm_bytes` counts each once (11 / 12 / 11 distinct tensors per constraint / variable /
-    # cut row: 5 X operands and 6 / 7 / 6 D operands) plus the raw features, the segment offsets and the partial slabs it
-    # writes; `hbm_bytes_per_job` charges every job its own operands (13 / 15 / 13 per row: 6 / 7 / 6 products + the first
-    # embedding layer's dE1; its ReLU pattern is 8 B per row) -- what the launch would move if no second read hit L2.  PMC
-    # traffic (FETCH_SIZE + WRITE_SIZE) lies between.
-    wg_min = row * (11 * C + 12 * V + 11 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 12.0 * (C + V + K)
-    wg_job = row * (13 * C + 15 * V + 13 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 12.0 * (C + V + K)
-    wg_flops = mm * (6 * C + 7 * V + 6 * K) + 2.0 * 16 * 64 * (C + V + K)
+    # embedding X up to three products): `hbm_bytes` counts each once (10 / 11 / 10 distinct tensors per constraint / variable /
+    # cut row: 4 X operands and 6 / 7 / 6 D operands -- the first embedding layer's output E1 is not among them: the forward
+    # pass does not store it, its product's job recomputes it from the raw features) plus the raw features, the segment offsets
+    # and the partial slabs it writes; `hbm_bytes_per_job` charges every job its own operands (12 / 14 / 12 per row: 6 / 7 / 6
+    # products less the recomputed operand + the first embedding layer's dE1, whose ReLU pattern is 8 B per row; the raw features
+    # twice) -- what the launch would move if no second read hit L2.  PMC traffic (FETCH_SIZE + WRITE_SIZE) lies between.
+    wg_min = row * (10 * C + 11 * V + 10 * K) + 4.0 * (4 * C + 14 * V + 6 * K) + 12.0 * (C + V + K)
+    wg_job = row * (12 * C + 14 * V + 12 * K) + 8.0 * (4 * C + 14 * V + 6 * K) + 12.0 * (C + V + K)
+    wg_flops = mm * (6 * C + 7 * V + 6 * K) + 2.0 * 16 * 64 * (C + V + K) + 2.0 * 64 * (4 * C + 16 * V + 8 * K)
     edge_f = lambda e, own, oth: 8.0 * e + row * (own + oth) + 2 * row * own    # tables in, S + N out, (index, coef) per edge
     edge_b = lambda e, own, oth: 8.0 * e + row * (own + 2 * oth) + row * own    # P_send, P_recv + dS in, dP_send out
     model_of = {
-        ("k_embed_fwd", 0): ("3 embeddings + 4 projections", V * (56 + 4 * row + 16) + C * (16 + 3 * row + 16) + K * (24 + 3 * row + 16),
+        ("k_embed_fwd", 0): ("3 embeddings + 4 projections", V * (56 + 3 * row + 16) + C * (16 + 2 * row + 16) + K * (24 + 2 * row + 16),
                              V * (2 * 14 * 64 + 3 * mm) + C * (2 * 4 * 64 + 2 * mm) + K * (2 * 6 * 64 + 2 * mm), 0),
         ("k_edge_fwd<count>", 0): ("conv v->c edge pass", edge_f(E1, C, V), 14.0 * 64 * E1, row * E1),
         ("k_conv_fwd<proj>", 0): ("conv v->c receiver update (C rows)", C * (5 * row + 16), C * 4 * mm, 0),
@@ -257,7 +258,7 @@ def roofline_step(model, batch, targets, dev, steps=20):
         ("k_conv_bwd", 1): ("conv v->c receiver gradients (C rows)", C * (7 * row + 16), C * 4 * mm, 0),
         ("k_edge_bwd_send", 2): ("conv v->c sender gradients", edge_b(E1, V, C), 22.0 * 64 * E1, 2 * row * E1),
         ("k_tail_bwd", 0): ("embedding tails (V and C rows)", V * (5 * row + 8) + C * (4 * row + 8), V * 3 * mm + C * 2 * mm, 0),
-        ("k_wgrad", 0): ("19 weight-gradient products + 3 first layers", wg_min, wg_flops, 0),
+        ("k_wgrad", 0): ("19 weight-gradient products (3 of them recomputing their operand E1) + 3 first layers", wg_min, wg_flops, 0),
     }
     pmc = step_traffic(d)
     out = []

@@ -245,10 +245,10 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
         float** pv[] = {&t->E1v, &t->Xv, &t->PR1, &t->PR2, &t->S2, &t->A2, &t->Z1v, &t->Xv2, &t->PR3};
         float** pk[] = {&t->E1k, &t->Xk, &t->PL3, &t->S3, &t->A3, &t->Z1k, &t->Xk2, &t->O1};
         // (no gradient of A exists since the layers around it are folded, k_rows.hpp Program 2; A itself stays: PreNorm fitting
-        // materialises it)
-        for (auto p : pc) *p = (pass && p == &t->A1) ? nullptr : take(C * EMB);
-        for (auto p : pv) *p = (pass && p == &t->A2) ? nullptr : take(V * EMB);
-        for (auto p : pk) *p = (pass && p == &t->A3) ? nullptr : take(K * EMB);
+        // materialises it.  No E1 activation either: the weight-gradient launch recomputes it, k_wgrad.hpp EXTRA == 3; its gradient stays)
+        for (auto p : pc) *p = ((pass && p == &t->A1) || (!pass && p == &t->E1c)) ? nullptr : take(C * EMB);
+        for (auto p : pv) *p = ((pass && p == &t->A2) || (!pass && p == &t->E1v)) ? nullptr : take(V * EMB);
+        for (auto p : pk) *p = ((pass && p == &t->A3) || (!pass && p == &t->E1k)) ? nullptr : take(K * EMB);
     }
     {
         mask16** mc[] = {&w->m.E1c, &w->m.Xc, &w->m.Z1c, &w->m.Xc2};
@@ -751,16 +751,16 @@ static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_fe
     // independent programs, one grouped launch
     {
         EmbGroupArgs m; memset(&m, 0, sizeof(m));
-        auto emb = [&](EmbArgs& e, const float* x, int pb, float* e1, float* xo, int n, mask16* me1, mask16* mx) {
+        auto emb = [&](EmbArgs& e, const float* x, int pb, float* xo, int n, mask16* me1, mask16* mx) {
             e.x = x; e.shift = p + poff(pb + E_SHIFT); e.scale = p + poff(pb + E_SCALE); e.w1 = p + poff(pb + E_W1);
-            e.b1 = p + poff(pb + E_B1); e.e1 = save ? e1 : nullptr; e.w2 = p + poff(pb + E_W2); e.b2 = p + poff(pb + E_B2);
+            e.b1 = p + poff(pb + E_B1); e.e1 = nullptr; e.w2 = p + poff(pb + E_W2); e.b2 = p + poff(pb + E_B2);
             e.xo = xo; e.n = n; e.m_e1 = save ? me1 : nullptr; e.m_x = save ? mx : nullptr;
         };
-        emb(m.v, var_feats, P_VAR, A.E1v, A.Xv, d->n_vars, w.m.E1v, w.m.Xv);    // variables: E1 -> Xv -> PR1, PR2 (model.py:294-295)
+        emb(m.v, var_feats, P_VAR, A.Xv, d->n_vars, w.m.E1v, w.m.Xv);    // variables: E1 -> Xv -> PR1, PR2 (model.py:294-295)
         m.v.wp[0] = p + poff(P_CONV0 + C_WR); m.v.po[0] = A.PR1; m.v.wp[1] = p + poff(P_CONV1 + C_WR); m.v.po[1] = A.PR2;
-        emb(m.c, cons_feats, P_CONS, A.E1c, A.Xc, d->n_cons, w.m.E1c, w.m.Xc);  // constraints: E1 -> Xc -> PL1
+        emb(m.c, cons_feats, P_CONS, A.Xc, d->n_cons, w.m.E1c, w.m.Xc);  // constraints: E1 -> Xc -> PL1
         m.c.wp[0] = p + poff(P_CONV0 + C_WL); m.c.bp[0] = p + poff(P_CONV0 + C_BL); m.c.po[0] = A.PL1;
-        emb(m.k, cut_feats, P_CUT, A.E1k, A.Xk, d->n_cuts, w.m.E1k, w.m.Xk);    // cuts: E1 -> Xk -> PL3
+        emb(m.k, cut_feats, P_CUT, A.Xk, d->n_cuts, w.m.E1k, w.m.Xk);    // cuts: E1 -> Xk -> PL3
         m.k.wp[0] = p + poff(P_CONV2 + C_WL); m.k.bp[0] = p + poff(P_CONV2 + C_BL); m.k.po[0] = A.PL3;
         const int convs[3] = {P_CONV0, P_CONV1, P_CONV2};     // the folded weights of the three convolutions ride in this launch
         for (int k = 0; k < 3; ++k) {
@@ -886,7 +886,8 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
 
 
 // ---- backward ---------------------------------------------------------------------------------------------------
-struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; const mask16* mask; const float *shift, *scale; int f; };
+struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; const mask16* mask; const float *shift, *scale; int f;
+                const float *w1, *b1; int f2; };
 struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
@@ -897,14 +898,20 @@ struct JobList {
 static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr,
                    int n, float* gw, float* gb, float* g2, float* /*partial*/) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
-    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2, nullptr, nullptr, nullptr, 0};
+    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
 }
 // first layer of an embedding: x = raw features [n][f], dmat = dE1 (unmasked), e1 = the ReLU pattern of the layer's output
 // (k_wgrad.hpp, EXTRA == 2)
 static void add_wg_emb1(JobList& jl, const float* x, const float* shift, const float* scale, const float* dmat, const mask16* e1,
                         int n, int f, float* gw, float* gb) {
     if (n <= 0) return;
-    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f};
+    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f, nullptr, nullptr, 0};
+}
+// second layer of an embedding with its input E1 recomputed from the raw features (k_wgrad.hpp, EXTRA == 3): dmat = dX
+static void add_wg_emb2(JobList& jl, const float* x, const float* shift, const float* scale, const float* w1, const float* b1,
+                        const float* dmat, int n, int f, float* gw, float* gb) {
+    if (n <= 0) return;
+    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, nullptr, shift, scale, 0, w1, b1, f};
 }
 // Order the collected jobs and give them their block ranges.  Several jobs read the same matrix (dZ1 feeds the gradients of
 // both halves of W1; a raw embedding X is the operand of up to three products): such jobs are placed next to each other and
@@ -928,8 +935,16 @@ static void place_wg(JobList& jl, float* partial) {
     // same length from start to end, so the MFMA pipes stay shared evenly and there is no second, partly filled round.
     // Smallest chunk (a multiple of 16 rows, at least WG_ROWS) whose block count fits; each job then spreads its rows evenly.
     // (every job needs at least one block, so fewer slots than jobs -- a device with a handful of CUs -- can never be met)
+    // A job's rows count with its cost per row in sixteenths of the plain product's (64 MFMAs and 512 B per 16 rows): the first
+    // embedding layer's job issues 16 MFMAs and reads 320 B, the recomputing job 64 + 4 * ceil(f/4) MFMAs and <= 312 B
+    // (10/16 and (16 + ceil(f/4))/16 measured best on capfac, setcov and indset batches: profiles/README.md, round 3).
     const int slots = std::max(std::min(2 * device_cus(), WG_MAX_SLABS - WG_MAX_JOBS), jl.npend);
-    auto blocks_at = [&](int r) { long long t = 0; for (int k = 0; k < jl.npend; ++k) t += cdiv(jl.pend[k].n, r * WG_WAVES); return t; };
+    const int cost2 = GCNN_KNOB("GCNN_WG_COST2", 10), cost3 = GCNN_KNOB("GCNN_WG_COST3", 16);
+    auto nblocks = [&](const PendWg& q, int r) {
+        const long long c = q.f ? cost2 : q.f2 ? cost3 + (q.f2 + 3) / 4 * GCNN_KNOB("GCNN_WG_COST3K", 1) : 16;
+        return (int)std::max<long long>(1, ((long long)q.n * c + 16LL * r * WG_WAVES - 1) / (16LL * r * WG_WAVES));
+    };
+    auto blocks_at = [&](int r) { long long t = 0; for (int k = 0; k < jl.npend; ++k) t += nblocks(jl.pend[k], r); return t; };
     int rows = WG_ROWS;
     if (blocks_at(rows) > slots) {   // bisect on multiples of 16
         int lo = rows / 16, hi = lo;
@@ -942,10 +957,10 @@ static void place_wg(JobList& jl, float* partial) {
     for (int k = 0; k < jl.npend; ++k) {
         const PendWg& q = jl.pend[order[k]];
         WgJob& j = jl.wg.job[jl.wg.njobs++];
-        const int nb = cdiv(q.n, rows * WG_WAVES);   // blocks = slabs: four chunks each
+        const int nb = std::min(nblocks(q, rows), cdiv(q.n, 16 * WG_WAVES));   // blocks = slabs: four chunks each
         j.nb = nb; j.rows = (cdiv(q.n, nb * WG_WAVES) + 15) & ~15;
         j.x = q.x; j.sx = q.sx; j.d = q.d; j.seg_ptr = q.seg_ptr; j.n = q.n; j.blk0 = jl.wg.nblocks; j.slab0 = jl.nslab;
-        j.mask = q.mask; j.shift = q.shift; j.scale = q.scale; j.f = q.f;
+        j.mask = q.mask; j.shift = q.shift; j.scale = q.scale; j.f = q.f; j.w1 = q.w1; j.b1 = q.b1; j.f2 = q.f2;
         const float* src = partial + (size_t)jl.nslab * WG_SLAB;
         jl.wg.nblocks += nb; jl.nslab += nb;
         auto rd = [&](const float* s, float* dst, int len) {
@@ -1055,10 +1070,10 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     if (d->n_cons <= 0 || d->n_vars <= 0 || d->n_cuts <= 0) HIPCHK(hipMemsetAsync(grads, 0, (size_t)g_ptotal * sizeof(float), st));
     if (d->n_cuts <= 0) return adam_after();  // no cut => every gradient is 0
     ConvIO cv[3]; conv_setup(cv, d, w, cg, kg);
-    struct { const float* x; const float* e1; const mask16* me1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
-        {cons_feats, A.E1c, w.m.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
-        {var_feats, A.E1v, w.m.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
-        {cut_feats, A.E1k, w.m.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
+    struct { const float* x; const mask16* me1; float* gx; float* ge1; int n; int pb; int f; } em[3] = {
+        {cons_feats, w.m.E1c, G.Xc, G.E1c, d->n_cons, P_CONS, 4},
+        {var_feats, w.m.E1v, G.Xv, G.E1v, d->n_vars, P_VAR, 14},
+        {cut_feats, w.m.E1k, G.Xk, G.E1k, d->n_cuts, P_CUT, 6}};
     // Dense(64->1) gradient (model.py:208): G.O1 = dscore (x) w2 masked by O1 > 0; dw2/db2 partials
     int head_parts = w.score_nblk;
     if (fused_head) {
@@ -1113,15 +1128,16 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     for (int i = 0; i < 3; ++i)   // kernel [f,64] and bias [64] are separate (4-float aligned) tensors in the layout
         add_wg_emb1(jl, em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), em[i].ge1, em[i].me1, em[i].n, em[i].f,
                     grads + poff(em[i].pb + E_W1), grads + poff(em[i].pb + E_B1));
-    for (int i = 0; i < 3; ++i)
-        add_wg(jl, em[i].e1, nullptr, em[i].gx, nullptr, em[i].n, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2), nullptr, w.partial);
+    for (int i = 0; i < 3; ++i)   // E1^T dX with E1 recomputed from the raw features: the forward pass does not store it
+        add_wg_emb2(jl, em[i].x, p + poff(em[i].pb + E_SHIFT), p + poff(em[i].pb + E_SCALE), p + poff(em[i].pb + E_W1), p + poff(em[i].pb + E_B1),
+                    em[i].gx, em[i].n, em[i].f, grads + poff(em[i].pb + E_W2), grads + poff(em[i].pb + E_B2));
     place_wg(jl, w.partial);
     if ((size_t)jl.nslab > wg_slabs(d)) return GCNN_E_WORKSPACE;
     for (int k = jl.ndw; k < 3; ++k) jl.dw.blk0[k + 1] = jl.dw.blk0[k];
     if (jl.wg.nblocks + jl.dw.blk0[3] > 0) {
         static PerDeviceOnce attr;
-        const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default
-        if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const size_t smem = (size_t)WG_WAVES * WG_SLAB * sizeof(float);   // 67.6 KB: above the 64 KB default (+ 3.8 KB static, k_wgrad.hpp: the attribute bounds the sum by 160 KB)
+        if (attr.first()) HIPCHK(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         ProfScope prof("k_wgrad", st);
         hipLaunchKernelGGL(k_wgrad, dim3(jl.wg.nblocks + jl.dw.blk0[3]), dim3(64 * WG_WAVES), smem, st, jl.wg, jl.dw);
         LAUNCHCHK();

@@ -26,26 +26,43 @@
 // f > 0: the job is the FIRST layer of an embedding, relu(((x+shift)*scale) @ W[f,64] + b) (model.py:174-177 and twins):
 //        x = the raw features [n][f], d = dE1 still unmasked, mask = the ReLU pattern of E1 (k_rows.hpp, mask16: 8 B per row);
 //        G is [f,64] (rows >= f: zeros)
+// f2 > 0: the job is the SECOND layer of an embedding, G = E1^T D with E1 = relu(((x+shift)*scale) @ W1[f2,64] + b1) -- the first
+//        layer's output is not stored by the forward pass (an [N,64] write, and this job's read of it, for something that f2 <= 14
+//        raw features determine): x = the raw features [n][f2], and E1 is recomputed 16 rows at a time (EXTRA == 3 below)
 struct WgJob { const float* x; const float* sx; const float* d; const int* seg_ptr; const unsigned short* mask; const float *shift, *scale;
-               int n; int blk0; int slab0; int f;
+               const float *w1, *b1;
+               int n; int blk0; int slab0; int f, f2;
                int nb, rows; };   // blocks of the job; rows per wave (a multiple of 16: the job's rows spread evenly over nb * 4 waves)
 struct WgArgs { int njobs; int nblocks; float* partial; WgJob job[WG_MAX_JOBS]; };
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
-struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS]; };   // p0 / p1: segment offsets (EXTRA 1) or the raw mask word (EXTRA 2)
+#define WG_KS_MAX 4   // raw features come in groups of four (one MFMA k-step): at most 14 of them
+struct WgBatch { float4 x[WG_STEPS], d[WG_STEPS]; int p0[WG_STEPS], p1[WG_STEPS];   // p0 / p1: segment offsets (EXTRA 1) or the raw mask word (EXTRA 2)
+                 float xr[WG_KS_MAX]; };                                           // EXTRA 3: raw features 4*ks + (lane >> 4) of row (lane & 15) of the batch
 
 // EXTRA: 0 = none, 1 = degree-weighted column sum of D (gradient of the hoisted b_f),
 //        2 = first embedding layer: X^T has only f <= 14 (padded to 16) rows, so lane (m, g) loads ONE raw feature x[row][m]
 //            (normalised at use) as the A operand of the single accumulator row, and D is masked by the layer's output
+//        3 = second embedding layer with X = E1 recomputed: per batch of 16 rows the wave evaluates the tile
+//            E1[16 rows][64] = relu(Xn[16][F] W1[F][64] + b1) with ceil(F/4) * 4 MFMAs (A: lane (j, k) holds the normalised feature
+//            4*ks + k of row j; B: the lane's W1 entries, loop invariant, in registers), and the tile passes through the wave's own
+//            LDS region into the operand layout (row 4*step + g, columns 4m..4m+3).  The forward program sums the same F products
+//            with a VALU FMA chain: the recomputed E1 equals the forward's up to fp32 rounding (~1e-7 relative)
 // Loads are UNCONDITIONAL (rows past the chunk are clamped to its last row and zeroed at use): a load under a branch would
 // make the number of loads in flight unknown to the compiler, which then waits for all of them (s_waitcnt vmcnt(0)) right
 // after issuing the next batch -- no overlap with the MFMAs at all.
-template <int EXTRA>
+template <int EXTRA, int F>
 __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, int rend, int g, int col) {
+    if (EXTRA == 3) {
+        const size_t r = (size_t)min(row0 + (int)(threadIdx.x & 15), rend - 1) * F;
+#pragma unroll
+        for (int ks = 0; ks < (F + 3) / 4; ++ks) t.xr[ks] = jb.x[r + min(4 * ks + g, F - 1)];   // features >= F: scale 0 at use
+    }
 #pragma unroll
     for (int s = 0; s < WG_STEPS; ++s) {
         const int r = min(row0 + 4 * s + g, rend - 1);   // callers guarantee rend > 0
-        if (EXTRA == 2) {
+        if (EXTRA == 3) {
+        } else if (EXTRA == 2) {
             t.x[s] = make_float4(jb.x[(size_t)r * jb.f + min(col >> 2, jb.f - 1)], 0.f, 0.f, 0.f);   // lanes m >= f: scale 0 below
             // columns 4m..4m+3 of row r (m = col/4 = 4a + b) are nibble a of the word at mask[r][b] (bit 4a+i <-> feature 16a+4b+i);
             // kept raw here (decoding would wait for the load), decoded at use
@@ -56,7 +73,8 @@ __device__ __forceinline__ void wg_load(WgBatch& t, const WgJob& jb, int row0, i
     }
 }
 
-template <int EXTRA>
+#define WG_SCR 68   // padded row of the EXTRA == 3 scratch tile (floats)
+template <int EXTRA, int F = 1>
 __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, int rend) {   // slab: this wave's LDS region
     const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4, col = 4 * m;
     f32x4w acc[4][4];
@@ -65,11 +83,43 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ce = cs;
     float shift = 0.f, scale = 0.f;   // EXTRA == 2: this lane's feature (m); features >= f contribute zeros
     if (EXTRA == 2 && m < jb.f) { shift = jb.shift[m]; scale = jb.scale[m]; }
+    // EXTRA == 3, loop invariant: lane (j = m, k = g) holds W1[4*ks + k][16*blk + j], b1[16*blk + j], and shift / scale of its features
+    constexpr int KS = EXTRA == 3 ? (F + 3) / 4 : 1;
+    float w1r[KS][4], b1r[4], sh3[KS], sc3[KS];
+    if (EXTRA == 3) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int f = 4 * ks + g;
+            const bool in = f < F;
+            sh3[ks] = in ? jb.shift[f] : 0.f; sc3[ks] = in ? jb.scale[f] : 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) w1r[ks][blk] = in ? jb.w1[f * EMB + 16 * blk + m] : 0.f;
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) b1r[blk] = jb.b1[16 * blk + m];
+    }
     auto compute = [&](const WgBatch& cur, int row0) {
+        if (EXTRA == 3) {   // E1 of the batch's 16 rows, into the wave's scratch tile (the wave's LDS operations complete in order)
+            f32x4w ev[4];
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) ev[blk] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float xn = (cur.xr[ks] + sh3[ks]) * sc3[ks];
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) ev[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(xn, w1r[ks][blk], ev[blk], 0, 0, 0);
+            }
+            // ev[blk][t] = E1[row 4g + t][16*blk + m]: banks (4g+t) * 68 + 16*blk + m are distinct over the 64 lanes
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) slab[(4 * g + t) * WG_SCR + 16 * blk + m] = fmaxf(ev[blk][t] + b1r[blk], 0.f);
+        }
 #pragma unroll
         for (int s = 0; s < WG_STEPS; ++s) {
             const bool live = row0 + 4 * s + g < rend;
-            float xa[4] = {cur.x[s].x, cur.x[s].y, cur.x[s].z, cur.x[s].w};
+            const float4 xs = EXTRA == 3 ? *(const float4*)(slab + (4 * s + g) * WG_SCR + col) : cur.x[s];
+            float xa[4] = {xs.x, xs.y, xs.z, xs.w};
             float db[4] = {cur.d[s].x, cur.d[s].y, cur.d[s].z, cur.d[s].w};
 #pragma unroll
             for (int v = 0; v < 4; ++v) { xa[v] = live ? xa[v] : 0.f; db[v] = live ? db[v] : 0.f; }
@@ -100,12 +150,12 @@ __device__ __forceinline__ void wg_body(const WgJob& jb, float* slab, int rbeg, 
     WgBatch ring[WG_RING];
     if (rbeg < rend) {   // (an empty chunk stores a zero slab)
 #pragma unroll
-        for (int u = 0; u < WG_RING - 1; ++u) wg_load<EXTRA>(ring[u], jb, rbeg + u * BR, rend, g, col);
+        for (int u = 0; u < WG_RING - 1; ++u) wg_load<EXTRA, F>(ring[u], jb, rbeg + u * BR, rend, g, col);
     }
     for (int row0 = rbeg; row0 < rend; row0 += WG_RING * BR) {
 #pragma unroll
         for (int u = 0; u < WG_RING; ++u) {
-            wg_load<EXTRA>(ring[(u + WG_RING - 1) % WG_RING], jb, row0 + (u + WG_RING - 1) * BR, rend, g, col);   // past the chunk: its last row again, unused
+            wg_load<EXTRA, F>(ring[(u + WG_RING - 1) % WG_RING], jb, row0 + (u + WG_RING - 1) * BR, rend, g, col);   // past the chunk: its last row again, unused
             __builtin_amdgcn_sched_barrier(0);
             if (row0 + u * BR < rend) compute(ring[u], row0 + u * BR);
             __builtin_amdgcn_sched_barrier(0);
@@ -157,7 +207,7 @@ __device__ __forceinline__ void dw_reduce_block(const DwRedArgs& d, int b, float
     if (part == 0) d.dst[c][(size_t)chunk * EMB + col] = (red[col] + red[EMB + col]) + (red[2 * EMB + col] + red[3 * EMB + col]);
 }
 
-__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, DwRedArgs dw) {
+__global__ __launch_bounds__(64 * WG_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad(WgArgs a, DwRedArgs dw) {
     extern __shared__ __attribute__((aligned(16))) float wg_red[];   // [WG_WAVES][WG_SLAB]
     const int ndw = dw.blk0[3];
     if ((int)blockIdx.x < ndw) {   // the d w_edge pre-reduction first: a few short blocks, out of the way before the long chunks fill the chip
@@ -181,7 +231,11 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(WgArgs a, DwRedArgs dw)
     if (lb >= jb.nb) lb -= jb.nb;
     const int rbeg = min(jb.n, (lb * WG_WAVES + wv) * jb.rows), rend = min(jb.n, rbeg + jb.rows);   // may be empty: zeros
     float* mine = wg_red + wv * WG_SLAB;
-    if (jb.f) wg_body<2>(jb, mine, rbeg, rend);
+    if (jb.f2) {   // (one job per block: uniform)
+        if (jb.f2 == 14) wg_body<3, 14>(jb, mine, rbeg, rend);
+        else if (jb.f2 == 6) wg_body<3, 6>(jb, mine, rbeg, rend);
+        else wg_body<3, 4>(jb, mine, rbeg, rend);
+    } else if (jb.f) wg_body<2>(jb, mine, rbeg, rend);
     else if (jb.seg_ptr) wg_body<1>(jb, mine, rbeg, rend);
     else wg_body<0>(jb, mine, rbeg, rend);
     __syncthreads();
