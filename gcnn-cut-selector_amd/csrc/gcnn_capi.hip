@@ -223,8 +223,7 @@ struct Work {
     float* dwp[3];        // per-block partials of d w_edge, one [GCNN_EDGE_DW_PARTS,64] array per convolution
     float* dwp2[3];       // ... and their pre-reduction to [GCNN_EDGE_DW_PARTS / DW_CHUNK, 64] (k_wgrad's third block type)
     float* nrow[3];          // per receiver and channel: number of active edges
-    float* fuse[3];          // folded weights of each convolution: M [64,64] | u [64]  (fuse_weights)
-    float* gfuse[3];         // their raw gradients out of the weight-gradient launch: G1 [64,64] | g2 [64]  (k_fold_grads)
+    float* fuse[3];          // folded weights of each convolution: M [64,64] | u [64], and copies of Wf, W1a, bf  (fuse_weights)
     float* score_partial; int score_nblk;
     double* stats; int* stat_ids;   // pretraining: per-block partial sums; explicit left ids of an edge set
     size_t total;
@@ -263,7 +262,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
     for (int i = 0; i < 3; ++i) {
         w->dwp[i] = take((size_t)GCNN_EDGE_DW_PARTS * EMB); w->dwp2[i] = take((size_t)(GCNN_EDGE_DW_PARTS / DW_CHUNK) * EMB);
         w->nrow[i] = take(nrecv[i] * EMB);
-        w->fuse[i] = take(FUSE_FLOATS); w->gfuse[i] = take(FUSE_FLOATS);
+        w->fuse[i] = take(FUSE_FLOATS);
     }
     w->stats = (double*)take(2 * (size_t)(ST_MAX_BLOCKS * ST_MAX_UNITS + 2 * ST_MAX_UNITS));
     w->stat_ids = (int*)take((size_t)std::max(d->n_cons_edges, d->n_cut_edges));
@@ -673,7 +672,7 @@ struct ConvIO {           // one PartialGraphConvolution instance (model.py:201-
     float *PL, *PR, *S, *A, *Z1, *OUT;
     float *gPL, *gPR, *gS, *gA, *gZ1, *gOUT, *gXL, *gXV, *DWP, *DWP2;
     float* N;
-    float *FZ, *GFZ;       // folded weights M | u and their raw gradients G1 | g2
+    float* FZ;             // folded weights M | u
     mask16 *mZ1, *mOUT;    // ReLU patterns of Z1 and OUT
 };
 
@@ -717,11 +716,11 @@ static int conv_forward(const float* p, const ConvIO& c, bool save, hipStream_t 
 static void conv_setup(ConvIO cv[3], const gcnn_dims* d, const Work& w, const gcnn_graph* cg, const gcnn_graph* kg) {
     const Acts &A = w.a, &G = w.g;
     cv[0] = ConvIO{P_CONV0, A.Xc, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, true, cg, P_CONS_EDGE,
-                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0], w.fuse[0], w.gfuse[0], w.m.Z1c, w.m.Xc2};
+                   A.PL1, A.PR1, A.S1, A.A1, A.Z1c, A.Xc2, G.PL1, G.PR1, G.S1, G.A1, G.Z1c, G.Xc2, G.Xc, G.Xv, w.dwp[0], w.dwp2[0], w.nrow[0], w.fuse[0], w.m.Z1c, w.m.Xc2};
     cv[1] = ConvIO{P_CONV1, A.Xc2, A.Xv, d->n_cons, d->n_vars, d->n_cons_edges, false, cg, P_CONS_EDGE,
-                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1], w.fuse[1], w.gfuse[1], w.m.Z1v, w.m.Xv2};
+                   A.PL2, A.PR2, A.S2, A.A2, A.Z1v, A.Xv2, G.PL2, G.PR2, G.S2, G.A2, G.Z1v, G.Xv2, G.Xc2, G.Xv, w.dwp[1], w.dwp2[1], w.nrow[1], w.fuse[1], w.m.Z1v, w.m.Xv2};
     cv[2] = ConvIO{P_CONV2, A.Xk, A.Xv2, d->n_cuts, d->n_vars, d->n_cut_edges, true, kg, P_CUT_EDGE,
-                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2], w.fuse[2], w.gfuse[2], w.m.Z1k, w.m.Xk2};
+                   A.PL3, A.PR3, A.S3, A.A3, A.Z1k, A.Xk2, G.PL3, G.PR3, G.S3, G.A3, G.Z1k, G.Xk2, G.Xk, G.Xv2, w.dwp[2], w.dwp2[2], w.nrow[2], w.fuse[2], w.m.Z1k, w.m.Xk2};
 }
 
 static int check_common(const gcnn_dims* d, const float* params, const gcnn_graph* cg, const gcnn_graph* kg,
@@ -887,31 +886,32 @@ extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float
 
 // ---- backward ---------------------------------------------------------------------------------------------------
 struct PendWg { const float *x, *sx, *d; const int* seg_ptr; int n; float *gw, *gb, *g2; const mask16* mask; const float *shift, *scale; int f;
-                const float *w1, *b1; int f2; };
+                const float *w1, *b1; int f2;
+                int fold; };   // > 0: the job's G and degree-weighted column sum stay in its slabs for fold entry (fold - 1) (fold_block, k_wgrad.hpp)
 struct JobList {
     WgArgs wg; RdArgs rd; int nslab;
     int rdblk;
     DwRedArgs dw; int ndw;   // d w_edge pre-reductions (one per convolution with edge-gradient partials)
-    FoldArgs fold;           // convolutions whose folded-layer gradients k_fold_grads has to unfold
+    FoldArgs fold;           // convolutions whose folded-layer gradients the front blocks of the k_reduce launch unfold
     PendWg pend[WG_MAX_JOBS]; int npend;   // weight-gradient jobs as collected; ordered and placed by place_wg
 };
 static void add_wg(JobList& jl, const float* x, const float* sx, const float* dmat, const int* seg_ptr,
                    int n, float* gw, float* gb, float* g2, float* /*partial*/) {
     if (n <= 0) return;  // empty input: gradients are exactly zero
-    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
+    jl.pend[jl.npend++] = PendWg{x, sx, dmat, seg_ptr, n, gw, gb, g2, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0};
 }
 // first layer of an embedding: x = raw features [n][f], dmat = dE1 (unmasked), e1 = the ReLU pattern of the layer's output
 // (k_wgrad.hpp, EXTRA == 2)
 static void add_wg_emb1(JobList& jl, const float* x, const float* shift, const float* scale, const float* dmat, const mask16* e1,
                         int n, int f, float* gw, float* gb) {
     if (n <= 0) return;
-    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f, nullptr, nullptr, 0};
+    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, e1, shift, scale, f, nullptr, nullptr, 0, 0};
 }
 // second layer of an embedding with its input E1 recomputed from the raw features (k_wgrad.hpp, EXTRA == 3): dmat = dX
 static void add_wg_emb2(JobList& jl, const float* x, const float* shift, const float* scale, const float* w1, const float* b1,
                         const float* dmat, int n, int f, float* gw, float* gb) {
     if (n <= 0) return;
-    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, nullptr, shift, scale, 0, w1, b1, f};
+    jl.pend[jl.npend++] = PendWg{x, nullptr, dmat, nullptr, n, gw, gb, nullptr, nullptr, shift, scale, 0, w1, b1, f, 0};
 }
 // Order the collected jobs and give them their block ranges.  Several jobs read the same matrix (dZ1 feeds the gradients of
 // both halves of W1; a raw embedding X is the operand of up to three products): such jobs are placed next to each other and
@@ -968,7 +968,8 @@ static void place_wg(JobList& jl, float* partial) {
             r.src = s; r.dst = dst; r.nparts = nb; r.stride = WG_SLAB; r.len = len; r.blk0 = jl.rdblk;
             jl.rdblk += cdiv(len, EMB);
         };
-        rd(src, q.gw, (q.f ? q.f : EMB) * EMB);   // first-layer kernel [f,64]: the first f rows of the slab
+        if (q.fold) { jl.fold.slab[q.fold - 1] = src; jl.fold.nparts[q.fold - 1] = nb; }   // summed by the blocks that consume it
+        else rd(src, q.gw, (q.f ? q.f : EMB) * EMB);   // first-layer kernel [f,64]: the first f rows of the slab
         if (q.gb) rd(src + EMB * EMB, q.gb, EMB);
         if (q.g2) rd(src + EMB * EMB + EMB, q.g2, EMB);
     }
@@ -1014,13 +1015,15 @@ static int conv_backward_edges(const float* p, float* grads, const ConvIO& c, co
     const int* seg = c.recv_left ? c.g->l_ptr : c.g->v_ptr;
     add_wg(jl, c.Z1, nullptr, c.gOUT, nullptr, nr, grads + poff(c.pbase + C_W2), grads + poff(c.pbase + C_B2), nullptr, w.partial);
     // the folded layers: ONE product S^T dZ1 (-> G1) with the column sum (-> d b1) and the degree-weighted column sum (-> g2) of
-    // dZ1; k_fold_grads turns G1 | g2 into the gradients of Wf, bf and the upper half of W1 (the two-layer form needed A^T dZ1 and
+    // dZ1; fold_block turns G1 | g2 into the gradients of Wf, bf and the upper half of W1 (the two-layer form needed A^T dZ1 and
     // S^T dA: two products, and A and dA in memory)
     if (nr > 0) {
-        add_wg(jl, c.S, nullptr, c.gZ1, seg, nr, c.GFZ, grads + poff(c.pbase + C_B1), c.GFZ + EMB * EMB, w.partial);
+        add_wg(jl, c.S, nullptr, c.gZ1, seg, nr, nullptr, grads + poff(c.pbase + C_B1), nullptr, w.partial);
         const int k = jl.fold.n++;
-        jl.fold.g1[k] = c.GFZ; jl.fold.wf[k] = p + poff(c.pbase + C_WF); jl.fold.bf[k] = p + poff(c.pbase + C_BF);
-        jl.fold.w1a[k] = p + poff(c.pbase + C_W1); jl.fold.s2[k] = p + poff(c.pbase + C_S2);
+        jl.pend[jl.npend - 1].fold = k + 1;
+        // (the forward's copies of Wf, bf, W1a: the launch that reads them also applies Adam to the originals)
+        jl.fold.wf[k] = c.FZ + FUSE_WF; jl.fold.bf[k] = c.FZ + FUSE_BF;
+        jl.fold.w1a[k] = c.FZ + FUSE_W1A; jl.fold.s2[k] = p + poff(c.pbase + C_S2);
         jl.fold.gwf[k] = grads + poff(c.pbase + C_WF); jl.fold.gbf[k] = grads + poff(c.pbase + C_BF); jl.fold.gw1a[k] = grads + poff(c.pbase + C_W1);
     }
     add_wg(jl, xrecv, nullptr, c.gZ1, nullptr, nr, grads + poff(c.pbase + C_W1) + EMB * EMB, nullptr, nullptr, w.partial);
@@ -1144,15 +1147,9 @@ extern "C" int gcnn_backward(const gcnn_dims* d, const float* p, const float* co
     }
     const bool fuse_adam = adam && d->n_cons > 0 && d->n_vars > 0 && jl.rdblk > 0;
     if (fuse_adam) jl.rd.adam = RdAdam{adam->params, adam->m, adam->v, grads, g_ptotal, adam->lr_t, adam->beta1, adam->beta2, adam->eps};
-    if (jl.rdblk > 0) {
+    if (jl.rdblk + jl.fold.n > 0) {   // front blocks: G1 | g2 -> gradients of Wf, bf, W1a (fold_block), with the same Adam update
         ProfScope prof(fuse_adam ? "k_reduce<adam>" : "k_reduce", st);
-        hipLaunchKernelGGL(k_reduce, dim3(jl.rdblk), dim3(256), 0, st, jl.rd);
-        LAUNCHCHK();
-    }
-    if (jl.fold.n > 0) {   // G1 | g2 -> gradients of Wf, bf, W1a (with their Adam update when k_reduce carried everyone else's)
-        jl.fold.adam = jl.rd.adam;
-        ProfScope prof(fuse_adam ? "k_fold_grads<adam>" : "k_fold_grads", st);
-        hipLaunchKernelGGL(k_fold_grads, dim3(9 * jl.fold.n), dim3(256), 0, st, jl.fold);
+        hipLaunchKernelGGL(k_reduce, dim3(FOLD_BLOCKS * jl.fold.n + jl.rdblk), dim3(256), 0, st, jl.rd, jl.fold);
         LAUNCHCHK();
     }
     return fuse_adam ? 0 : adam_after();

@@ -307,8 +307,13 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
 }
 // The folded weights of the three convolutions (Program 2): M = s2 * Wf * W1a [64,64] followed by u = s2 * bf * W1a [64], FUSE_FLOATS
 // floats per convolution.  One 256-thread block each, riding in the embedding launch (the first consumer is the third launch
-// of a forward pass); exact fp32 FMA chains in k order.  smem: 2 * 64 * LDW floats.
-#define FUSE_FLOATS (EMB * EMB + EMB)
+// of a forward pass); exact fp32 FMA chains in k order.  smem: 2 * 64 * LDW floats.  Behind M | u the block leaves copies of Wf, W1a
+// and bf as they were in this forward pass: the blocks that turn the folded gradients into those of Wf, W1a and bf (fold_block,
+// k_wgrad.hpp) ride in the launch whose Adam updates overwrite these parameters, so they read the copies.
+#define FUSE_WF (EMB * EMB + EMB)
+#define FUSE_W1A (FUSE_WF + EMB * EMB)
+#define FUSE_BF (FUSE_W1A + EMB * EMB)
+#define FUSE_FLOATS (FUSE_BF + EMB)
 struct FuseArgs { const float *wf[3], *bf[3], *s2[3], *w1a[3]; float* out[3]; };
 __device__ __forceinline__ void fuse_weights(const FuseArgs& f, const int k, float* smem) {
     float* wfs = smem;                  // Wf  [i][LDW]
@@ -316,9 +321,13 @@ __device__ __forceinline__ void fuse_weights(const FuseArgs& f, const int k, flo
     const int t = threadIdx.x;
     if (t < 256) {
         for (int q = t; q < 1024; q += 256) {
-            *(float4*)(wfs + (q >> 4) * LDW + (q & 15) * 4) = *(const float4*)(f.wf[k] + q * 4);
-            *(float4*)(was + (q >> 4) * LDW + (q & 15) * 4) = *(const float4*)(f.w1a[k] + q * 4);
+            const float4 a = *(const float4*)(f.wf[k] + q * 4), b = *(const float4*)(f.w1a[k] + q * 4);
+            *(float4*)(wfs + (q >> 4) * LDW + (q & 15) * 4) = a;
+            *(float4*)(was + (q >> 4) * LDW + (q & 15) * 4) = b;
+            *(float4*)(f.out[k] + FUSE_WF + q * 4) = a;
+            *(float4*)(f.out[k] + FUSE_W1A + q * 4) = b;
         }
+        if (t < EMB) f.out[k][FUSE_BF + t] = f.bf[k][t];
     }
     __syncthreads();
     if (t >= 256) return;

@@ -259,16 +259,132 @@ struct RdJob { const float* src; float* dst; int nparts; int stride; int len; in
 struct RdAdam { float* p; float* m; float* v; const float* gbase; int gn; float lr_t, b1, b2, eps; };
 struct RdArgs { int njobs; float* cdst; float cval; RdAdam adam; RdJob job[RD_MAX_JOBS]; };   // cdst (optional): a constant the launch also stores
 
-__global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
-    __shared__ float red[4][EMB];
-    if (a.cdst && blockIdx.x == 0 && threadIdx.x == 0) *a.cdst = a.cval;
+// ---------------------------------------------------------------------------------------------------------------
+// Gradients of the folded layers (k_rows.hpp, Program 2): the forward uses M = s2*Wf*W1a and u = s2*bf*W1a, the weight-gradient
+// launch leaves, per convolution, partial slabs of G1 = S^T dZ1 [64,64] and g2 = sum_r deg_r dZ1[r] [64] (one job instead of the
+// two that needed A and dA).  By the chain rule through M and u:
+//   dWf  = s2 * G1 W1a^T          dW1a = s2 * (Wf^T G1 + bf (x) g2)          dbf = s2 * W1a g2
+// A few 64^3 products on reduced data, done by FOLD_BLOCKS blocks per convolution at the front of the k_reduce launch (a launch
+// of its own behind k_reduce cost 6.8 us per step): 16 blocks for four rows of dWf each, 16 for four columns of dW1a each, one
+// for dbf.  A block adds up exactly the 4 x 64 entries of G1 its outputs need straight from the job's slabs -- 64 float4 positions
+// x 4 groups of slabs, a handful of loads per thread, all in flight together with the weight matrix it stages through LDS: one
+// memory round trip -- in a fixed order (slabs p, p+4, ... per group, then (g0+g1)+(g2+g3), like k_reduce).  Carries the Adam
+// update of these entries when the backward pass was asked to apply it (k_reduce does the same for every other gradient).
+// ---------------------------------------------------------------------------------------------------------------
+struct FoldArgs { const float* slab[3]; int nparts[3]; const float *wf[3], *bf[3], *w1a[3], *s2[3]; float *gwf[3], *gbf[3], *gw1a[3]; int n; };
+#define FOLD_BLOCKS 33
+#define FOLD_LDS_FLOATS (EMB * LDW + 1024 + 256 + 2 * EMB)   // a [64,64] matrix | partial sums | the slice of G1 | g2, bf
+// sum over the slabs p = first, first + step, ... of the float4 at element offset `off`; eight loads in flight, unconditional
+// (a slab index past the end re-reads the last slab and is dropped)
+__device__ __forceinline__ float4 fold_chain(const float* __restrict__ slab, int np, int first, int step, int off) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = first; p < np; p += 8 * step) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(slab + (size_t)min(p + u * step, np - 1) * WG_SLAB + off);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p + u * step < np) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    return s;
+}
+__device__ __forceinline__ float4 f4_add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ void fold_block(const FoldArgs& a, const RdAdam& adam, const int b, float* lds) {
+    float* big = lds;                        // a whole [64,64] weight matrix, rows padded to LDW
+    float4* psum = (float4*)(lds + EMB * LDW);   // [4][64] (dbf block: [16][16]) partial sums
+    float* sl = lds + EMB * LDW + 1024;      // the block's 4 x 64 entries of G1
+    float* sv = sl + 256;                    // g2 | bf
+    const int c = b / FOLD_BLOCKS, part = b % FOLD_BLOCKS, t = threadIdx.x;
+    const float s2 = *a.s2[c];
+    const float* slab = a.slab[c];
+    const int np = a.nparts[c];
+    auto emit = [&](float* dst, float gi) {
+        *dst = gi;
+        const long long idx = dst - adam.gbase;
+        if (adam.p && idx >= 0 && idx < adam.gn) {
+            const float mi = adam.b1 * adam.m[idx] + (1.f - adam.b1) * gi;
+            const float vi = adam.b2 * adam.v[idx] + (1.f - adam.b2) * gi * gi;
+            adam.m[idx] = mi; adam.v[idx] = vi;
+            adam.p[idx] -= adam.lr_t * mi / (sqrtf(vi) + adam.eps);
+        }
+    };
+    const float* wsrc = (part >= 16 && part < 32) ? a.wf[c] : a.w1a[c];
+    float4 tw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tw[q] = *(const float4*)(wsrc + (q * 256 + t) * 4);
+    const int pos = t & 63, pg = t >> 6;
+    if (part < 16) {           // dWf[i][j] = s2 * sum_k G1[i][k] * W1a[j][k], rows i = 4*part .. 4*part+3
+        const float4 g = fold_chain(slab, np, pg, 4, (4 * part + (pos >> 4)) * EMB + (pos & 15) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // W1a transposed ([k][j]): the loop below reads consecutive j across the lanes
+            const int idx = q * 256 + t, r = idx >> 4, col = (idx & 15) * 4;
+            big[(col + 0) * LDW + r] = tw[q].x; big[(col + 1) * LDW + r] = tw[q].y; big[(col + 2) * LDW + r] = tw[q].z; big[(col + 3) * LDW + r] = tw[q].w;
+        }
+        psum[pg * 64 + pos] = g;
+        __syncthreads();
+        if (t < 64) *(float4*)(sl + 4 * t) = f4_add(f4_add(psum[t], psum[64 + t]), f4_add(psum[128 + t], psum[192 + t]));   // sl[ii][k]
+        __syncthreads();
+        const int ii = t >> 6, j = t & 63;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < EMB; ++k) acc = fmaf(sl[ii * EMB + k], big[k * LDW + j], acc);
+        emit(a.gwf[c] + (4 * part + ii) * EMB + j, s2 * acc);
+    } else if (part < 32) {    // dW1a[j][k] = s2 * (sum_i Wf[i][j] * G1[i][k] + bf[j] * g2[k]), columns k = k0 .. k0+3
+        const int k0 = 4 * (part - 16);
+        const float4 g = fold_chain(slab, np, pg, 4, pos * EMB + k0);
+        float4 g2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pos == 0) g2 = fold_chain(slab, np, pg, 4, EMB * EMB + EMB + k0);
+        const float vb = t < EMB ? a.bf[c][t] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int idx = q * 256 + t; *(float4*)(big + (idx >> 4) * LDW + (idx & 15) * 4) = tw[q]; }   // Wf[i][j]
+        psum[pg * 64 + pos] = g;
+        if (pos == 0) ((float4*)sv)[pg] = g2;   // sv[0..15]: the four groups' sums of g2[k0..k0+3]; bf behind them
+        if (t < EMB) sv[EMB + t] = vb;
+        __syncthreads();
+        if (t < 64) *(float4*)(sl + 4 * t) = f4_add(f4_add(psum[t], psum[64 + t]), f4_add(psum[128 + t], psum[192 + t]));   // sl[i][kk]
+        __syncthreads();
+        const int j = t >> 2, kk = t & 3;
+        const float4 g2s = f4_add(f4_add(((const float4*)sv)[0], ((const float4*)sv)[1]), f4_add(((const float4*)sv)[2], ((const float4*)sv)[3]));
+        const float g2k = kk == 0 ? g2s.x : kk == 1 ? g2s.y : kk == 2 ? g2s.z : g2s.w;
+        float acc = sv[EMB + j] * g2k;
+#pragma unroll 8
+        for (int i = 0; i < EMB; ++i) acc = fmaf(big[i * LDW + j], sl[4 * i + kk], acc);
+        emit(a.gw1a[c] + j * EMB + k0 + kk, s2 * acc);
+    } else {                   // dbf[j] = s2 * sum_k W1a[j][k] * g2[k]
+        const int p16 = t & 15, g16 = t >> 4;
+        const float4 g = fold_chain(slab, np, g16, 16, EMB * EMB + EMB + 4 * p16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int idx = q * 256 + t; *(float4*)(big + (idx >> 4) * LDW + (idx & 15) * 4) = tw[q]; }   // W1a[j][k]
+        psum[g16 * 16 + p16] = g;
+        __syncthreads();
+        if (t < 16) {
+            float4 s = psum[t];
+            for (int q = 1; q < 16; ++q) s = f4_add(s, psum[q * 16 + t]);
+            *(float4*)(sv + 4 * t) = s;
+        }
+        __syncthreads();
+        if (t < EMB) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < EMB; ++k) acc = fmaf(big[t * LDW + k], sv[k], acc);
+            emit(a.gbf[c] + t, s2 * acc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce(RdArgs a, FoldArgs f) {
+    __shared__ __attribute__((aligned(16))) float lds[FOLD_LDS_FLOATS];
+    if ((int)blockIdx.x < FOLD_BLOCKS * f.n) { fold_block(f, a.adam, blockIdx.x, lds); return; }   // the longest blocks first
+    float (*red)[EMB] = (float (*)[EMB])lds;
+    const int bid = blockIdx.x - FOLD_BLOCKS * f.n;
+    if (a.cdst && bid == 0 && threadIdx.x == 0) *a.cdst = a.cval;
     int ji = 0;   // binary search over up to 96 jobs
     for (int hi = a.njobs; hi - ji > 1;) {
         const int mid = (ji + hi) >> 1;
-        if ((int)blockIdx.x >= a.job[mid].blk0) ji = mid; else hi = mid;
+        if (bid >= a.job[mid].blk0) ji = mid; else hi = mid;
     }
     const RdJob jb = a.job[ji];
-    const int chunk = blockIdx.x - jb.blk0;
+    const int chunk = bid - jb.blk0;
     const int col = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int e = chunk * EMB + col;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -298,74 +414,3 @@ __global__ __launch_bounds__(256) void k_reduce(RdArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Gradients of the folded layers (k_rows.hpp, Program 2): the forward uses M = s2*Wf*W1a and u = s2*bf*W1a, the weight-gradient
-// launch leaves, per convolution, G1 = S^T dZ1 [64,64] and g2 = sum_r deg_r dZ1[r] [64] (one job instead of the two that needed
-// A and dA).  By the chain rule through M and u:
-//   dWf  = s2 * G1 W1a^T          dW1a = s2 * (Wf^T G1 + bf (x) g2)          dbf = s2 * W1a g2
-// A few 64^3 products on reduced data: 9 blocks per convolution (four 16-row slices of dWf, four of dW1a, one for dbf), straight
-// from global memory (everything is L2-resident), fixed summation order; carries the Adam update of these entries when the
-// backward pass was asked to apply it (k_reduce does the same for every other gradient).
-// ---------------------------------------------------------------------------------------------------------------
-struct FoldArgs { const float *g1[3], *wf[3], *bf[3], *w1a[3], *s2[3]; float *gwf[3], *gbf[3], *gw1a[3]; int n; RdAdam adam; };
-__global__ __launch_bounds__(256) void k_fold_grads(FoldArgs a) {
-    // G1 and the one weight matrix a block needs go through LDS, every global load issued before the first LDS write: one memory
-    // round trip per block (read in the loops below, the same 64 dependent L2 round trips made the launch 13 us long)
-    __shared__ __attribute__((aligned(16))) float sg[EMB * LDW], sw[EMB * LDW], sv[2 * EMB];
-    const int c = blockIdx.x / 9, part = blockIdx.x % 9, t = threadIdx.x;
-    const float s2 = *a.s2[c];
-    const float* wsrc = (part >= 4 && part < 8) ? a.wf[c] : a.w1a[c];
-    float4 tg[4], tw[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { tg[q] = *(const float4*)(a.g1[c] + (q * 256 + t) * 4); tw[q] = *(const float4*)(wsrc + (q * 256 + t) * 4); }
-    const float vg = t < EMB ? a.g1[c][EMB * EMB + t] : (t < 2 * EMB ? a.bf[c][t - EMB] : 0.f);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = q * 256 + t, r = idx >> 4, col = (idx & 15) * 4;
-        *(float4*)(sg + r * LDW + col) = tg[q];
-        if (part < 4) {   // W1a transposed ([k][j]): the loop below reads four consecutive j per thread
-            sw[(col + 0) * LDW + r] = tw[q].x; sw[(col + 1) * LDW + r] = tw[q].y; sw[(col + 2) * LDW + r] = tw[q].z; sw[(col + 3) * LDW + r] = tw[q].w;
-        } else *(float4*)(sw + r * LDW + col) = tw[q];
-    }
-    if (t < 2 * EMB) sv[t] = vg;      // g2 | bf
-    __syncthreads();
-    auto emit = [&](float* dst, float gi) {
-        *dst = gi;
-        const long long idx = dst - a.adam.gbase;
-        if (a.adam.p && idx >= 0 && idx < a.adam.gn) {
-            const float mi = a.adam.b1 * a.adam.m[idx] + (1.f - a.adam.b1) * gi;
-            const float vi = a.adam.b2 * a.adam.v[idx] + (1.f - a.adam.b2) * gi * gi;
-            a.adam.m[idx] = mi; a.adam.v[idx] = vi;
-            a.adam.p[idx] -= a.adam.lr_t * mi / (sqrtf(vi) + a.adam.eps);
-        }
-    };
-    if (part < 4) {            // dWf[i][j] = s2 * sum_k G1[i][k] * W1a[j][k]
-        const int i = 16 * part + (t >> 4), j0 = (t & 15) * 4;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int k = 0; k < EMB; ++k) {
-            const float g = sg[i * LDW + k];
-            const float4 w = *(const float4*)(sw + k * LDW + j0);
-            acc[0] = fmaf(g, w.x, acc[0]); acc[1] = fmaf(g, w.y, acc[1]); acc[2] = fmaf(g, w.z, acc[2]); acc[3] = fmaf(g, w.w, acc[3]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) emit(a.gwf[c] + i * EMB + j0 + q, s2 * acc[q]);
-    } else if (part < 8) {     // dW1a[j][k] = s2 * (sum_i Wf[i][j] * G1[i][k] + bf[j] * g2[k])
-        const int j = 16 * (part - 4) + (t >> 4), k0 = (t & 15) * 4;
-        const float b = sv[EMB + j];
-        float acc[4] = {b * sv[k0], b * sv[k0 + 1], b * sv[k0 + 2], b * sv[k0 + 3]};
-#pragma unroll 8
-        for (int i = 0; i < EMB; ++i) {
-            const float w = sw[i * LDW + j];
-            const float4 g = *(const float4*)(sg + i * LDW + k0);
-            acc[0] = fmaf(w, g.x, acc[0]); acc[1] = fmaf(w, g.y, acc[1]); acc[2] = fmaf(w, g.z, acc[2]); acc[3] = fmaf(w, g.w, acc[3]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) emit(a.gw1a[c] + j * EMB + k0 + q, s2 * acc[q]);
-    } else if (t < EMB) {      // dbf[j] = s2 * sum_k W1a[j][k] * g2[k]
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < EMB; ++k) acc = fmaf(sw[t * LDW + k], sv[k], acc);
-        emit(a.gbf[c] + t, s2 * acc);
-    }
-}
