@@ -23,7 +23,7 @@ def step_records(path, name):
         k = int(r["Dispatch_Id"])
         by_dispatch.setdefault(k, [r["Kernel_Name"].split("(")[0].replace("void ", ""), 0.0])[1] += float(r["Counter_Value"])
     steps, cur, live = [], [], False
-    for kern, val in by_dispatch.values():   # a step: k_embed_fwd ... up to its last launch (k_fold_grads, or k_reduce when nothing follows it)
+    for kern, val in by_dispatch.values():   # a step: k_embed_fwd ... up to its last launch (k_reduce; k_fold_grads behind it in profiles of earlier builds)
         if live and (kern.startswith("k_embed_fwd") or not kern.startswith("k_")):
             steps.append(cur)
             live = False

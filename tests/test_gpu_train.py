@@ -365,3 +365,29 @@ def test_few_tile_programs_give_the_same_bits_as_the_one_wave_programs(dev):
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([l for l in r.stdout.splitlines() if l.startswith("BITS")][-1])
     assert out[0] == out[1]
+
+
+def test_fused_adam_steps_are_bitwise_reproducible_and_equal_the_unfused_update(dev):
+    """The blocks that unfold the folded layers' gradients (fold_block, k_wgrad.hpp) ride in the launch whose Adam updates
+    overwrite Wf, W1a and bf: they must read the forward pass's copies of those parameters.  Three fused steps from the same
+    state, twice: the same bits; and one fused step equals gradients first, Adam afterwards (model_trainer.py:271-276)."""
+    from gcnn_cut_selector_amd.trainer import Adam, TrainState, train_step
+    state, y, _ = synthetic.make_batch("setcov", 8)
+    outs = []
+    for rep in range(3):
+        m, _ = _model(31, dev)
+        batch = m.prepare(state)
+        yt = torch.as_tensor(y).to(dev)
+        opt, ts = Adam(learning_rate=lambda: 1e-3), TrainState(m)
+        if rep < 2:
+            for _ in range(3):
+                train_step(m, batch, yt, opt, ts)
+            outs.append(m.flat_parameters.detach().cpu().numpy().copy())
+        else:   # one step: fused against gradients-then-Adam on a second copy of the model
+            m2, _ = _model(31, dev)
+            opt2, ts2 = Adam(learning_rate=lambda: 1e-3), TrainState(m2)
+            train_step(m, batch, yt, opt, ts)
+            train_step(m2, m2.prepare(state), yt, None, ts2)
+            opt2.apply_flat(m2, ts2.grads)
+            np.testing.assert_allclose(m.flat_parameters.detach().cpu().numpy(), m2.flat_parameters.detach().cpu().numpy(), rtol=1e-6, atol=1e-9)
+    assert np.array_equal(outs[0], outs[1])
