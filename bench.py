@@ -428,7 +428,7 @@ def main():
 
     launch = "eager"
     if args.graph:
-        try:  # the whole step (16 launches, the all-reduce) as one hipGraph replay
+        try:  # the whole step (15 launches, the all-reduce) as one hipGraph replay
             step = GraphedTrainStep(model, batch, targets, opt, ts, process_group=group)
             launch = "hipGraph replay"
         except Exception as exc:  # capture not possible (e.g. a collective that cannot be captured): stay eager

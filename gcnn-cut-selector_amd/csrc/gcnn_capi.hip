@@ -10,7 +10,7 @@
 //   sum_e (H_e W_f + b_f) = (sum_e H_e) W_f + deg_r b_f
 // so the edge pass only gathers rows, applies ReLU and accumulates in registers (atomic-free segmented sum over
 // receiver-sorted CSR); all 64x64 products run on the fp32 MFMA (v_mfma_f32_16x16x4_f32; weights in LDS for the row
-// programs, operands straight from global memory for the weight gradients).  A training step is 16 launches on one stream.
+// programs, operands straight from global memory for the weight gradients).  A training step is 15 launches on one stream.
 // Wavefront = 64 lanes everywhere.  No atomics on floats anywhere: every sum has a fixed order => bitwise
 // reproducible results.
 

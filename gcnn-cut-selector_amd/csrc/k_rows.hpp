@@ -373,7 +373,7 @@ __global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
 //        M = s2*Wf*W1a and vector u = s2*bf*W1a (made once per forward by fuse_weights, riding in the embedding launch):
 //          Z1 = relu(S M + deg_r u + x_recv W1b + b1)
 //        -- a 64x64 product per receiver row less, and A is neither written nor read again (the backward pass folds the same
-//        way: dS = dZ1 M^T; the gradients of Wf, bf and W1a come out of S^T dZ1, see k_fold_grads).  KEEP_A = true is the
+//        way: dS = dZ1 M^T; the gradients of Wf, bf and W1a come out of S^T dZ1, see fold_block, k_wgrad.hpp).  KEEP_A = true is the
 //        two-layer form that materialises A: PreNorm fitting needs its statistics (model.py:503, 570).
 //   X' = relu(Z1 W2 + b2)                                                                          -> out
 //   TAIL = CF_PROJ   :  T = X' Wt (+ bt): the next convolution's projection                        -> t_out
