@@ -372,6 +372,7 @@ __device__ __forceinline__ void fold_block(const FoldArgs& a, const RdAdam& adam
     }
 }
 
+static_assert(sizeof(RdArgs) + sizeof(FoldArgs) <= 4096, "k_reduce: kernel arguments beyond the 4 KB a launch carries");
 __global__ __launch_bounds__(256) void k_reduce(RdArgs a, FoldArgs f) {
     __shared__ __attribute__((aligned(16))) float lds[FOLD_LDS_FLOATS];
     if ((int)blockIdx.x < FOLD_BLOCKS * f.n) { fold_block(f, a.adam, blockIdx.x, lds); return; }   // the longest blocks first
