@@ -118,6 +118,30 @@ __global__ __launch_bounds__(256) void k_ranking(const float* __restrict__ pred,
     const int s = blockIdx.x, beg = offsets[s], n = offsets[s + 1] - beg;
     if (s == 0 && threadIdx.x == 0 && loss_acc) *loss_acc += *loss_in * loss_weight;
     if (n <= 0) { if (threadIdx.x == 0 && frac_out) frac_out[s] = 0.f; return; }
+    if (n <= 256) {   // the usual case (a sample has a few dozen cuts): thread i counts the entries ranked before its own -- its
+        // position in the stable descending order -- in both lists; position r of the two orders differs exactly when the
+        // entry the prediction puts there has another position by the truth.  One barrier instead of a sorting network's 21-36.
+        const int i = threadIdx.x;
+        const bool in = i < n;
+        float a = in ? pred[beg + i] : -INFINITY, b = in ? truth[beg + i] : -INFINITY;
+        a = a != a ? -INFINITY : a; b = b != b ? -INFINITY : b;   // NaN ranks as -inf, as below
+        v[0][i] = a; v[1][i] = b;
+        if (i == 0) first_dev = n;
+        __syncthreads();
+        if (in) {
+            int ra = 0, rb = 0;
+            for (int j = 0; j < n; ++j) { ra += rk_before(v[0][j], j, a, i); rb += rk_before(v[1][j], j, b, i); }
+            if (ra != rb) atomicMin(&first_dev, ra);
+        }
+        __syncthreads();
+        if (i == 0) {
+            const float frac = (float)first_dev / (float)n;
+            if (frac_out) frac_out[s] = frac;
+            for (int f = 0; f < nfrac; ++f)
+                if (frac >= fractions[f]) atomicAdd(&acc[f], 1.0f);
+        }
+        return;
+    }
     int m = 1;
     while (m < n) m <<= 1;
     for (int i = threadIdx.x; i < m; i += 256) {

@@ -192,7 +192,7 @@ def test_device_ranking_metric_matches_reference_semantics(dev):
     """gcnn_ranking_metric vs the oracle's restatement of model_trainer.py:288-301, with many ties and ragged sample sizes."""
     from gcnn_cut_selector_amd.trainer import ranking_metric
     rng = np.random.default_rng(0)
-    n_cuts = np.array([1, 2, 3, 17, 64, 65, 100, 257, 1000, 4096, 5])
+    n_cuts = np.array([1, 2, 3, 17, 64, 65, 100, 255, 256, 257, 1000, 4096, 5])   # <= 256: rank by counting; above: the sorting network
     pred = [rng.integers(0, 6, n).astype(np.float32) for n in n_cuts]
     true = [p.copy() for p in pred]
     for p, t in zip(pred, true):             # perturb a suffix so prefixes of varying length agree
