@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- MUST be imported before the CDLL below: torch shi
 #                              would register the kernels with a second HIP runtime (hipErrorNoDevice at first launch)
 
 LIB_PATH = os.environ.get("GCNN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgcnn_hip.so")  # GCNN_LIB: A/B builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GcnnError(RuntimeError):
@@ -83,6 +83,7 @@ SIGNATURES = {
     "gcnn_ranking_metric": (C.c_int, [_P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _F, _P, _P]),
     "gcnn_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I, _P, _P, _I, _P]),
     "gcnn_host_sort_edges_by_row": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "gcnn_host_pack_edges": (C.c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
 }
 
 _lib = None

@@ -273,7 +273,7 @@ static void carve(const gcnn_dims* d, float* base, Work* w) {
 
 extern "C" {
 
-int gcnn_abi_version(void) { return 10; }
+int gcnn_abi_version(void) { return 11; }
 
 int gcnn_profile_begin(void) {
     int d = 0;
@@ -873,6 +873,20 @@ extern "C" int gcnn_host_sort_edges_by_row(const int32_t* rows, const int32_t* c
         out_inds[at] = rows[e]; out_inds[n_edges + at] = cols[e]; out_vals[at] = vals[e];
     }
     return 0;
+}
+
+// the usual case in one call: copy the list into the staging buffer and look at its order on the way; only a list that turns out
+// not to be sorted by row goes through the counting sort above
+extern "C" int gcnn_host_pack_edges(const int32_t* rows, const int32_t* cols, const float* vals, int32_t n_edges, int32_t n_left,
+                                    int32_t* out_inds, float* out_vals, int32_t* scratch) {
+    if (n_edges < 0 || n_left < 0 || (n_edges > 0 && (!rows || !cols || !vals || !out_inds || !out_vals || !scratch))) return GCNN_E_BADARG;
+    int unsorted = 0;
+    for (int e = 1; e < n_edges; ++e) unsorted |= rows[e] < rows[e - 1];
+    if (unsorted && gcnn_host_sort_edges_by_row(rows, cols, vals, n_edges, n_left, out_inds, out_vals, scratch) == 0) return 1;
+    memcpy(out_inds, rows, sizeof(int32_t) * (size_t)n_edges);            // sorted -- or a row id out of range: packed as it is,
+    memcpy(out_inds + n_edges, cols, sizeof(int32_t) * (size_t)n_edges);   // the device check reports it
+    memcpy(out_vals, vals, sizeof(float) * (size_t)n_edges);
+    return unsorted ? 2 : 0;
 }
 
 extern "C" int gcnn_forward_loss(const gcnn_dims* d, const float* p, const float* cons_feats, const float* var_feats,

@@ -131,10 +131,10 @@ class _InferenceSession:
             # flags catch everything that is out of range but representable)
             if ei.dtype != np.int32 and ei.size and (int(ei.max()) > 2 ** 31 - 1 or int(ei.min()) < -2 ** 31):
                 raise ValueError("edge index out of range (left ids must be in [0,n_left), variable ids in [0,n_vars))")
-        # The specialised plan wants lists sorted by row, which is what get_state emits (utils.py:102-104).  A list in another order
-        # is sorted while it is packed: a stable counting sort on the host (gcnn_host_sort_edges_by_row: tens of microseconds for
-        # a few 10^4 entries; NumPy's stable argsort alone would take longer than the whole general path).
-        unsorted = [ei.shape[1] > 1 and bool((ei[0, 1:] < ei[0, :-1]).any()) for ei in (cei, kei)]
+        # The specialised plan wants lists sorted by row, which is what get_state emits (utils.py:102-104).  Packing is one native
+        # pass per list (gcnn_host_pack_edges): copy into the staging buffer, look at the order on the way, and only a list in
+        # another order goes through a stable counting sort on the host (tens of microseconds for a few 10^4 entries; NumPy's
+        # stable argsort alone would take longer than the whole general path).
         key = (c.shape[0], v.shape[0], k.shape[0], cei.shape[1], kei.shape[1])
         lay = self._layout(key)
         if lay is False or (want_order and key[2] > 4096):
@@ -156,22 +156,17 @@ class _InferenceSession:
         for off, a, dt in ((in_off[1], c, np.float32), (in_off[4], v, np.float32), (in_off[5], k, np.float32)):
             if a.size:
                 np.copyto(buf[off:off + 4 * a.size].view(dt).reshape(a.shape), a, casting="unsafe")
-        for (io, fo, ei, ef, n_left), uns in zip(((in_off[2], in_off[3], cei, cef, key[0]), (in_off[6], in_off[7], kei, kef, key[2])), unsorted):
+        for io, fo, ei, ef, n_left in ((in_off[2], in_off[3], cei, cef, key[0]), (in_off[6], in_off[7], kei, kef, key[2])):
             if not ei.size:
                 continue
-            done = False
-            if uns:   # rows / cols / values as contiguous int32 / fp32, then one native pass into the staging buffer
-                ei32 = np.ascontiguousarray(ei, dtype=np.int32)
-                ef32 = np.ascontiguousarray(ef, dtype=np.float32).reshape(-1)
-                if self.sort_scratch is None or self.sort_scratch.size < n_left + 1:
-                    self.sort_scratch = np.empty(2 * (n_left + 1), np.int32)
-                rc = _lib.lib().gcnn_host_sort_edges_by_row(
-                    C.c_void_p(ei32.ctypes.data), C.c_void_p(ei32.ctypes.data + 4 * ei32.shape[1]), C.c_void_p(ef32.ctypes.data),
-                    ei32.shape[1], n_left, C.c_void_p(base + io), C.c_void_p(base + fo), C.c_void_p(self.sort_scratch.ctypes.data))
-                done = rc == 0            # a row id out of range: packed as it is, the device check raises
-            if not done:
-                np.copyto(buf[io:io + 4 * ei.size].view(np.int32).reshape(ei.shape), ei, casting="unsafe")
-                np.copyto(buf[fo:fo + 4 * ef.size].view(np.float32).reshape(ef.shape), ef, casting="unsafe")
+            ei32 = np.ascontiguousarray(ei, dtype=np.int32)                  # no copies for what get_state hands over
+            ef32 = np.ascontiguousarray(ef, dtype=np.float32).reshape(-1)
+            if self.sort_scratch is None or self.sort_scratch.size < n_left + 1:
+                self.sort_scratch = np.empty(2 * (n_left + 1), np.int32)
+            rc = _lib.lib().gcnn_host_pack_edges(ei32.ctypes.data, ei32.ctypes.data + 4 * ei32.shape[1], ef32.ctypes.data,
+                                                 ei32.shape[1], n_left, base + io, base + fo, self.sort_scratch.ctypes.data)
+            if rc < 0:      # (0 / 1 / 2: packed -- as it was, sorted here, or as it was with a row id the device check reports)
+                _lib.check(rc, "gcnn_host_pack_edges")
         t1 = time.perf_counter()
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev)

@@ -194,6 +194,12 @@ int gcnn_infer(const gcnn_dims* dims, const float* params, const void* host_in, 
  * Returns 0, or GCNN_E_BADARG when a row id lies outside [0, n_left) (nothing is written then: the device check reports it). */
 int gcnn_host_sort_edges_by_row(const int32_t* rows, const int32_t* cols, const float* vals, int32_t n_edges, int32_t n_left,
                                 int32_t* out_inds, float* out_vals, int32_t* scratch);
+/* The packing step itself, same arguments: copies the list into the staging buffer and checks its order on the way (one pass, no
+ * temporaries); a list that is not sorted by row goes through gcnn_host_sort_edges_by_row.  Returns 0 (was sorted: copied), 1
+ * (sorted here), 2 (not sorted and a row id outside [0, n_left): copied as it is, the device check of gcnn_infer reports it), or
+ * GCNN_E_BADARG for null pointers / negative sizes. */
+int gcnn_host_pack_edges(const int32_t* rows, const int32_t* cols, const float* vals, int32_t n_edges, int32_t n_left,
+                         int32_t* out_inds, float* out_vals, int32_t* scratch);
 
 /* Keras-form Adam step (see gcnn_adam_step) to run right behind a backward pass. */
 typedef struct gcnn_adam_args {

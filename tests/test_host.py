@@ -352,3 +352,33 @@ def test_out_of_memory_skips_a_batch_single_gpu_and_propagates_data_parallel(mon
     with pytest.raises(torch.OutOfMemoryError):
         trainer.process(FakeModel(), [batch, batch, batch], fractions, None, opt, process_group="group")
     assert calls == ["group", "group"]                                                            # stopped at the failing step
+
+
+def test_host_pack_edges_copies_sorted_lists_and_sorts_the_others_stably():
+    """gcnn_host_pack_edges (the host half of gcnn_infer: no device work): a (row, col)-sorted list as get_state emits it
+    (utils.py:102-104) is copied, any other order comes out as NumPy's stable sort by row, an unsorted list with a row id out of
+    range is copied as it is (the device check of gcnn_infer reports it)."""
+    import ctypes as C
+    from gcnn_cut_selector_amd import _lib
+    f = _lib.lib().gcnn_host_pack_edges
+    rng = np.random.default_rng(5)
+    for n_left, n in ((1, 1), (7, 40), (300, 5000), (50, 0)):
+        rows = np.sort(rng.integers(0, n_left, n)).astype(np.int32)
+        cols = rng.integers(0, 1000, n).astype(np.int32)
+        vals = rng.standard_normal(n).astype(np.float32)
+        scratch = np.empty(n_left + 1, np.int32)
+        for shuffled in (False, True):
+            if shuffled:
+                p = rng.permutation(n)
+                rows, cols, vals = rows[p].copy(), cols[p].copy(), vals[p].copy()
+            out_i, out_v = np.full(2 * n, -7, np.int32), np.full(n, np.nan, np.float32)
+            rc = f(rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, n, n_left, out_i.ctypes.data, out_v.ctypes.data, scratch.ctypes.data)
+            order = np.argsort(rows, kind="stable")
+            was_sorted = bool((np.diff(rows) >= 0).all())
+            assert rc == (0 if was_sorted else 1)
+            assert np.array_equal(out_i[:n], rows[order]) and np.array_equal(out_i[n:], cols[order]) and np.array_equal(out_v, vals[order])
+    rows, cols, vals = np.array([3, 9, 1], np.int32), np.array([0, 1, 2], np.int32), np.array([1, 2, 3], np.float32)
+    out_i, out_v, scratch = np.zeros(6, np.int32), np.zeros(3, np.float32), np.empty(6, np.int32)
+    assert f(rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, 3, 5, out_i.ctypes.data, out_v.ctypes.data, scratch.ctypes.data) == 2
+    assert np.array_equal(out_i, [3, 9, 1, 0, 1, 2]) and np.array_equal(out_v, vals)
+    assert f(None, None, None, 3, 5, None, None, None) == -1
