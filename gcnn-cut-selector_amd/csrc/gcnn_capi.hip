@@ -572,7 +572,7 @@ static int launch_embed_fwd(EmbGroupArgs& m, IplanArgs* plan, hipStream_t st) {
     // overlap the store-heavy epilogues with the MFMAs better than two (capfac x 32, indset x 64)
     const int cap_knob = GCNN_KNOB("GCNN_EMB_CAP", 0);
     const int tiles = cdiv(std::max(m.v.n, 0), 16) + cdiv(std::max(m.c.n, 0), 16) + cdiv(std::max(m.k.n, 0), 16);
-    const int cap = cap_knob > 0 ? cap_knob : (tiles >= 8192 ? 512 : 256);
+    const int cap = cap_knob > 0 ? cap_knob : (tiles >= 8192 ? 2 * device_cus() - 3 : 256);   // (- 3: the fuse_weights blocks are resident too)
     const int nwaves = rows_blocks(n, ns, 3, m.blk0, cap);
     if (plan) {
         const int nt = nwaves * 64;

@@ -355,8 +355,10 @@ __device__ __forceinline__ void fuse_weights(const FuseArgs& f, const int k, flo
 struct EmbGroupArgs { int blk0[4]; EmbArgs v, c, k; FuseArgs fz; };   // variables (F=14, two projections), constraints (4), cuts (6); blocks blk0[3] .. +2: fuse_weights
 #define EMB_LDS_FLOATS (ROWS_LDS_FLOATS(3, 4) + 14 * 64)
 static_assert(EMB_LDS_FLOATS >= 2 * 64 * LDW, "fuse_weights stages two matrices in the embedding launch's LDS");
+// Two blocks of this launch share a CU when the row sets are large (launch_embed_fwd: 52 KB of LDS each, four waves per SIMD with
+// 8-wave blocks), which takes at most 128 registers per lane: pinned, since two registers more silently halve the residency.
 template <int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void k_embed_fwd(EmbGroupArgs m) {
+__global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(NWAVES / 2, NWAVES / 2))) void k_embed_fwd(EmbGroupArgs m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     if (b < m.blk0[1]) emb_program<14, 2, NWAVES * 64>(m.v, smem, b, m.blk0[1]);
