@@ -752,7 +752,7 @@ static int forward_impl(const gcnn_dims* d, const float* p, const float* cons_fe
         EmbGroupArgs m; memset(&m, 0, sizeof(m));
         auto emb = [&](EmbArgs& e, const float* x, int pb, float* xo, int n, mask16* me1, mask16* mx) {
             e.x = x; e.shift = p + poff(pb + E_SHIFT); e.scale = p + poff(pb + E_SCALE); e.w1 = p + poff(pb + E_W1);
-            e.b1 = p + poff(pb + E_B1); e.e1 = nullptr; e.w2 = p + poff(pb + E_W2); e.b2 = p + poff(pb + E_B2);
+            e.b1 = p + poff(pb + E_B1); e.w2 = p + poff(pb + E_W2); e.b2 = p + poff(pb + E_B2);
             e.xo = xo; e.n = n; e.m_e1 = save ? me1 : nullptr; e.m_x = save ? mx : nullptr;
         };
         emb(m.v, var_feats, P_VAR, A.Xv, d->n_vars, w.m.E1v, w.m.Xv);    // variables: E1 -> Xv -> PR1, PR2 (model.py:294-295)

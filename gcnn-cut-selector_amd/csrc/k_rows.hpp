@@ -223,12 +223,12 @@ __device__ __forceinline__ void stage_lds(float* smem, const float* const (&w)[N
 
 // ---------------------------------------------------------------------------------------------------------------
 // Program 1 (forward): embedding + the projections of the raw embedding (model.py:174-198 applied :287-291; :486-496)
-//   E1 = relu(((x + shift) * scale) W1 + b1)   [VALU, K = F <= 14]      -> e1 (optional: kept for the backward pass)
+//   E1 = relu(((x + shift) * scale) W1 + b1)   [VALU, K = F <= 14]      (its ReLU pattern -> m_e1)
 //   X  = relu(E1 W2 + b2)                                               -> xo
 //   P_k = X Wp_k (+ bp_k)                        k < NPROJ               -> po[k]
 // ---------------------------------------------------------------------------------------------------------------
 struct EmbArgs {
-    const float *x, *shift, *scale, *w1, *b1; float* e1; mask16* m_e1;    // m_e1, m_x: ReLU patterns for the backward pass (optional)
+    const float *x, *shift, *scale, *w1, *b1; mask16* m_e1;    // m_e1, m_x: ReLU patterns for the backward pass (optional); E1 itself is never stored (k_wgrad.hpp rebuilds it)
     const float *w2, *b2; float* xo; mask16* m_x;
     const float* wp[2]; const float* bp[2]; float* po[2];
     int n;
@@ -288,7 +288,6 @@ __device__ __forceinline__ void emb_program(const EmbArgs& a, float* smem, int b
         }
         rt_bias<true>(o, vecs, g);
         rt_clear_unless(o, ok);
-        rt_store(o, a.e1, row, ok, g);
         rt_mask_store(o, a.m_e1, row, ok, g);
         rt_mm<false>(t, o, 1.f, smem, lane);
         rt_bias<true>(t, vecs + 64, g);

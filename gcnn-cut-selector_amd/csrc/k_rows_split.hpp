@@ -132,7 +132,6 @@ __device__ __forceinline__ void emb_split(const EmbArgs& a, float* smem, int bid
         }
         rq_bias<true>(q, vecs, L);
         rq_clear_unless(q, ok);
-        rq_store(q, a.e1, row, ok, L);
         rq_exchange(full, q, L);
         if (L.wv == 0) rt_mask_store(full, a.m_e1, row, ok, L.g);   // every wave holds the whole tile now: one of them writes its pattern
         rq_mm<GEMM_FWD>(q, full, 1.f, smem, L);
