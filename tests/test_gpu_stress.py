@@ -6,10 +6,11 @@ unsorted COO lists (any order is accepted; `get_state` emits (row, col)-sorted o
 Per case, against the fp64 oracle (edge semantics: /root/reference/model.py:563-575):
   * scores of `model(state)` and of the one-call inference path `score_state`: rtol = atol = 1e-4 (the north star's tolerance);
   * all 46 gradients of the autograd path: 1e-4 of each tensor's largest entry, or three times the distance of torch's own fp32
-    evaluation of the restatement from fp64 where that is larger (cancellation in d w_edge).  A tensor beyond that bound passes only
+    evaluation of the restatement from fp64 where that is larger (cancellation in d w_edge).  Tensors beyond that bound pass only
     under the single-column confinement rule: a ReLU pre-activation within rounding of zero may take the other branch in this
-    fp32 evaluation than in fp64, which moves ONE output column of one weight gradient by one row's share -- so all columns but
-    the worst must still be within the bound, and the worst within 5e-3;
+    fp32 evaluation than in fp64, which moves ONE output column of the weight gradients of that unit's layer by one row's share
+    (and, through the backward pass, every tensor of the layers before it by as much, over all columns) -- so one of the tensors
+    beyond the bound must have all columns but the worst within it, and none may be off by more than 5e-3;
   * the fused training step (forward + MSE head + cut-row turnaround in one launch, backward from there) against the autograd
     path: gradients rtol 1e-4, loss against the oracle;
   * the ranking `score_state(rank=True)` returns against Python's `sorted(range(n), key=..., reverse=True)` (model_evaluator.py:110)
@@ -111,15 +112,21 @@ def test_random_state_parity(dev, model, idx):
     _, want_loss, wg = O.loss_and_grads(p64, state, y, torch.float64)
     _, _, wg32 = O.loss_and_grads(params, state, y, torch.float32)
     assert abs(float(loss.detach()) - want_loss) <= 1e-4 * max(1.0, abs(want_loss))
+    beyond = []   # (tensor, largest error, confined to one column?)
     for name, g in zip([n for n, _, t in O.PARAM_SPEC if t], m.gradients()):
         g = g.cpu().numpy().astype(np.float64)
         ref = max(np.abs(wg[name]).max(), 1e-6)
         err = np.abs(g - wg[name]) / ref
         bound = max(1e-4, 3 * np.abs(wg32[name].astype(np.float64) - wg[name]).max() / ref) + 1e-7
-        if err.max() > bound:      # single-column confinement: one flipped ReLU unit moves one output column, nothing wider
+        if err.max() > bound:
             cols = err.reshape(-1, err.shape[-1]).max(0)
-            assert np.sort(cols)[-2] <= bound if cols.size > 1 else False, (name, float(err.max()), bound, np.sort(cols)[-4:])
-            assert err.max() <= 5e-3, (name, float(err.max()))
+            beyond.append((name, float(err.max()), bool(cols.size > 1 and np.sort(cols)[-2] <= bound)))
+    # single-column confinement: one flipped ReLU unit moves one output column of the weight gradients of ITS layer; the layers
+    # before it inherit the difference over all columns.  So errors beyond the bound need a tensor where they are confined to
+    # one column, and none may exceed 5e-3.
+    if beyond:
+        assert max(b[1] for b in beyond) <= 5e-3, beyond
+        assert any(b[2] for b in beyond), beyond
     # ---- the fused training step against the autograd path
     batch = m.prepare(state)
     ts = TrainState(m)
