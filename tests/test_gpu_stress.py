@@ -49,6 +49,8 @@ CASES = [
     (2, 5000, 1000, 4, 4, True, True, False),       # two constraint rows of thousands of entries
     (1200, 700, 15, 3, 300, True, False, True),
     (64, 64, 1024, 30, 30, True, True, False),
+    (70000, 300, 17, 1, 20, True, False, True),     # a long, thin constraint set: hundreds of rows per weight-gradient wave, row programs with many tiles per wave
+    (40, 66000, 33, 2, 3, True, False, False),      # ... and as many variable rows
 ]
 
 
