@@ -190,7 +190,7 @@ def roofline_scatter_sum(batch, dev):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and (e, r) == (800000, 16000):
             traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
-            source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this kernel and shape; not measured in this run)"
+            source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel and shape, committed under profiles/: counters cannot be read inside this process, so tools/collect_round.sh takes them right before the bench line on the same box and any other run of bench.py re-uses them)"
             break
     return {"kernel": "k_seg_sum (standalone scatter-sum pass, conv v->c shape; not on the fused training path)", "bound": "hbm",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -302,7 +302,7 @@ def step_traffic(d):
         if os.path.exists(path):
             rec = json.load(open(path))
             if rec.get("dims") == [d.n_cons, d.n_vars, d.n_cuts, d.n_cons_edges, d.n_cut_edges]:
-                rec["source"] = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this workload (FETCH_SIZE doubled per MI355X_MICROARCH.md); not measured in this run"
+                rec["source"] = f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload committed under profiles/ (FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be read inside this process, so tools/collect_round.sh takes them right before the bench line on the same box and any other run of bench.py re-uses them"
                 return rec
     return None
 
